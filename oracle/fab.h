@@ -1,0 +1,93 @@
+/*
+ * oracle/fab.h -- TEST INFRASTRUCTURE ONLY (CPU oracle for remora_amd).
+ *
+ * Minimal box / array helpers used by the CPU restatement of REMORA's
+ * TimeIntegration hot path.  Nothing in remora_amd/ may include or link this.
+ *
+ * The memory layout is the one REMORA sees through amrex::Array4
+ * (i fastest, then j, k, component slowest), which is also the on-disk FAB
+ * order of the gold plotfiles.
+ */
+#ifndef ORACLE_FAB_H
+#define ORACLE_FAB_H
+
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+typedef struct { int lo[3], hi[3]; } Box;
+
+typedef struct {
+    double *p;          /* element (lo[0],lo[1],lo[2],comp 0) */
+    int lo[3], hi[3];
+    int nc;
+    long sy, sz, sn;    /* strides in doubles: j, k, component */
+} Fab;
+
+static inline Box box_make(int l0,int l1,int l2,int h0,int h1,int h2)
+{ Box b={{l0,l1,l2},{h0,h1,h2}}; return b; }
+static inline int  box_ok(Box b){ return b.lo[0]<=b.hi[0] && b.lo[1]<=b.hi[1] && b.lo[2]<=b.hi[2]; }
+static inline Box  box_grow(Box b,int g0,int g1,int g2)
+{ b.lo[0]-=g0; b.hi[0]+=g0; b.lo[1]-=g1; b.hi[1]+=g1; b.lo[2]-=g2; b.hi[2]+=g2; return b; }
+static inline Box  box_growlo(Box b,int d,int n){ b.lo[d]-=n; return b; }
+static inline Box  box_growhi(Box b,int d,int n){ b.hi[d]+=n; return b; }
+/* cell -> nodal in direction d (amrex::surroundingNodes) */
+static inline Box  box_nodal(Box b,int d){ b.hi[d]+=1; return b; }
+static inline Box  box_slab(Box b,int d,int v){ b.lo[d]=v; b.hi[d]=v; return b; }
+static inline Box  box_and(Box a,Box b)
+{ for(int d=0;d<3;d++){ if(b.lo[d]>a.lo[d])a.lo[d]=b.lo[d]; if(b.hi[d]<a.hi[d])a.hi[d]=b.hi[d]; } return a; }
+static inline int  box_contains(Box b,int i,int j,int k)
+{ return i>=b.lo[0]&&i<=b.hi[0]&&j>=b.lo[1]&&j<=b.hi[1]&&k>=b.lo[2]&&k<=b.hi[2]; }
+static inline int  box_contains_box(Box a,Box b)
+{ return b.lo[0]>=a.lo[0]&&b.hi[0]<=a.hi[0]&&b.lo[1]>=a.lo[1]&&b.hi[1]<=a.hi[1]&&b.lo[2]>=a.lo[2]&&b.hi[2]<=a.hi[2]; }
+
+static inline Box fab_box(Fab f){ Box b; for(int d=0;d<3;d++){b.lo[d]=f.lo[d];b.hi[d]=f.hi[d];} return b; }
+
+static inline Fab fab_view(double *p, Box b, int nc)
+{
+    Fab f; f.p=p; f.nc=nc;
+    for(int d=0;d<3;d++){f.lo[d]=b.lo[d];f.hi[d]=b.hi[d];}
+    f.sy=(long)(b.hi[0]-b.lo[0]+1);
+    f.sz=f.sy*(long)(b.hi[1]-b.lo[1]+1);
+    f.sn=f.sz*(long)(b.hi[2]-b.lo[2]+1);
+    return f;
+}
+static inline long fab_size(Fab f){ return f.sn*(long)f.nc; }
+
+/* allocate; fill with NaN so that any read of never-written data shows up */
+static inline Fab fab_alloc(Box b,int nc)
+{
+    Fab f=fab_view(NULL,b,nc);
+    long n=fab_size(f);
+    f.p=(double*)malloc(sizeof(double)*(size_t)(n>0?n:1));
+    for(long q=0;q<n;q++) f.p[q]=NAN;
+    return f;
+}
+static inline void fab_free(Fab *f){ free(f->p); f->p=NULL; }
+static inline void fab_setval(Fab f,double v){ long n=fab_size(f); for(long q=0;q<n;q++) f.p[q]=v; }
+/* view starting at component n (MultiFab::array(mfi,n)) */
+static inline Fab fab_comp(Fab f,int n){ f.p+=f.sn*(long)n; f.nc-=n; return f; }
+
+#define IX(f,i,j,k)     ((long)((i)-(f).lo[0]) + (long)((j)-(f).lo[1])*(f).sy + (long)((k)-(f).lo[2])*(f).sz)
+#define V(f,i,j,k)      ((f).p[IX(f,i,j,k)])
+#define VN(f,i,j,k,n)   ((f).p[IX(f,i,j,k) + (long)(n)*(f).sn])
+
+/* loop over a box in the order amrex::ParallelFor uses on the CPU (k outer, i inner) */
+#define FORBOX(b,i,j,k) \
+    for(int k=(b).lo[2];k<=(b).hi[2];k++) \
+    for(int j=(b).lo[1];j<=(b).hi[1];j++) \
+    for(int i=(b).lo[0];i<=(b).hi[0];i++)
+#define FORBOX2D(b,i,j) \
+    for(int j=(b).lo[1];j<=(b).hi[1];j++) \
+    for(int i=(b).lo[0];i<=(b).hi[0];i++)
+
+/* std::max / std::min semantics (return first argument on ties / unordered) */
+static inline double dmax(double a,double b){ return (a<b)?b:a; }
+static inline double dmin(double a,double b){ return (b<a)?b:a; }
+
+static inline void fab_setval_box(Fab f,Box b,double v)
+{ b=box_and(b,fab_box(f)); for(int n=0;n<f.nc;n++) FORBOX(b,i,j,k) VN(f,i,j,k,n)=v; }
+static inline void fab_copy(Fab dst,int dc,Fab src,int sc,int nc,Box b)
+{ for(int n=0;n<nc;n++) FORBOX(b,i,j,k) VN(dst,i,j,k,dc+n)=VN(src,i,j,k,sc+n); }
+
+#endif

@@ -1,0 +1,136 @@
+"""ctypes wrapper of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+
+
+class Params(C.Structure):
+    _fields_ = [("ncell", C.c_int * 3), ("prob_lo", C.c_double * 3), ("prob_hi", C.c_double * 3),
+                ("periodic", C.c_int * 2), ("slipwall", C.c_int * 2), ("fixed_dt", C.c_double), ("ndtfast", C.c_int),
+                ("flat_bathymetry", C.c_int), ("tracer_c4", C.c_int), ("uv_c2", C.c_int), ("use_coriolis", C.c_int),
+                ("use_prestep", C.c_int), ("use_uv3dmix", C.c_int), ("use_barotropic", C.c_int), ("use_salt", C.c_int),
+                ("g", C.c_double), ("rho0", C.c_double), ("R0", C.c_double), ("T0", C.c_double), ("S0", C.c_double),
+                ("Tcoef", C.c_double), ("Scoef", C.c_double), ("theta_s", C.c_double), ("theta_b", C.c_double),
+                ("tcline", C.c_double), ("rdrag", C.c_double), ("coriolis_f0", C.c_double), ("coriolis_beta", C.c_double),
+                ("hmix_constant", C.c_int), ("visc2", C.c_double), ("tnu2", C.c_double * 3), ("prob", C.c_int),
+                ("u_0", C.c_double), ("v_0", C.c_double), ("threads", C.c_int)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
+            for f in ("leaves.c", "bc.c", "driver.c", "oracle.h", "fab.h")):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+        _lib.o_create.restype = C.c_void_p
+        _lib.o_create.argtypes = [C.POINTER(Params)]
+        for f in ("o_destroy", "o_advance", "o_setup_step", "o_advance_3d_ml", "o_begin_step", "o_end_step"):
+            getattr(_lib, f).argtypes = [C.c_void_p]
+            getattr(_lib, f).restype = None
+        _lib.o_advance_2d_onestep.argtypes = [C.c_void_p, C.c_int]
+        _lib.o_nfast.argtypes = [C.c_void_p]
+        _lib.o_istep.argtypes = [C.c_void_p]
+        _lib.o_field.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(C.c_double)), C.c_int * 3, C.c_int * 3,
+                                 C.POINTER(C.c_int)]
+        _lib.o_plot.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _lib.o_set_weights.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def make_params(case, threads=1):
+    from remora_amd.cases import PROB
+    p = Params()
+    for k, v in case.items():
+        if k == "prob":
+            p.prob = PROB[v]
+        elif isinstance(v, (tuple, list)):
+            arr = getattr(p, k)
+            for i, x in enumerate(v):
+                arr[i] = x
+        else:
+            setattr(p, k, v)
+    p.slipwall[0] = 0 if case["periodic"][0] else 1
+    p.slipwall[1] = 0 if case["periodic"][1] else 1
+    p.threads = threads
+    return p
+
+
+class Oracle:
+    def __init__(self, case, threads=1):
+        self.case = case
+        self.p = make_params(case, threads)
+        self.h = lib().o_create(C.byref(self.p))
+        self.ncell = tuple(case["ncell"])
+
+    def close(self):
+        if self.h:
+            lib().o_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def nfast(self):
+        return lib().o_nfast(self.h)
+
+    @property
+    def istep(self):
+        return lib().o_istep(self.h)
+
+    def advance(self, n=1):
+        for _ in range(n):
+            lib().o_advance(self.h)
+
+    def begin_step(self): lib().o_begin_step(self.h)
+    def end_step(self): lib().o_end_step(self.h)
+    def setup_step(self): lib().o_setup_step(self.h)
+    def advance_2d_onestep(self, iif): lib().o_advance_2d_onestep(self.h, iif)
+    def advance_3d_ml(self): lib().o_advance_3d_ml(self.h)
+
+    def field(self, name):
+        """numpy view [comp, k, j, i] on the oracle's grown array, plus (lo, hi)."""
+        p = C.POINTER(C.c_double)()
+        lo = (C.c_int * 3)()
+        hi = (C.c_int * 3)()
+        nc = C.c_int()
+        if not lib().o_field(self.h, name.encode(), C.byref(p), lo, hi, C.byref(nc)):
+            raise KeyError(name)
+        shp = (nc.value, hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1)
+        a = np.ctypeslib.as_array(p, shape=(int(np.prod(shp)),)).reshape(shp)
+        return a, tuple(lo), tuple(hi)
+
+    def plot(self, with_scalar=False):
+        nx, ny, nz = self.ncell
+        nc = 6 if with_scalar else 5
+        out = np.empty((nc, nz, ny, nx))
+        lib().o_plot(self.h, int(with_scalar), out.ctypes.data)
+        return out
+
+
+def set_weights(ndtfast):
+    w1 = np.zeros(2 * ndtfast + 1)
+    w2 = np.zeros(2 * ndtfast + 1)
+    nfast = lib().o_set_weights(ndtfast, w1.ctypes.data, w2.ctypes.data)
+    return nfast, w1, w2

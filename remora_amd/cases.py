@@ -1,0 +1,52 @@
+"""Run configurations of the pinned cases, restated from the reference's test inputs.
+
+Pure data (no compute): each dict mirrors Tests/test_files/<case>/<case>.i of the reference plus
+the SolverChoice defaults of Source/REMORA_DataStruct.H:351-483 it leaves untouched.
+`scaled()` produces the roofline / scaling variants named in BASELINE.json (same physics, more cells).
+"""
+import copy
+
+PROB = {"Upwelling": 0, "Seamount": 1, "DoubleGyre": 2, "Advection": 3}
+
+_DEFAULTS = dict(
+    flat_bathymetry=1, tracer_c4=0, uv_c2=0, use_coriolis=0, use_prestep=1, use_uv3dmix=1,
+    use_barotropic=1, use_salt=1, g=9.81, rho0=1025.0, R0=1028.0, T0=5.0, S0=35.0, Tcoef=1.7e-4,
+    Scoef=0.0, theta_s=3.0, theta_b=0.0, tcline=150.0, rdrag=3e-4, coriolis_f0=0.0, coriolis_beta=0.0,
+    hmix_constant=0, visc2=0.0, tnu2=(0.0, 0.0, 0.0), u_0=0.0, v_0=0.0,
+)
+
+CASES = {
+    # Tests/test_files/Upwelling/Upwelling.i
+    "Upwelling": dict(_DEFAULTS, prob="Upwelling", ncell=(41, 80, 16), prob_lo=(0., 0., -150.), prob_hi=(41000., 80000., 0.),
+                      periodic=(1, 0), fixed_dt=300.0, ndtfast=30, flat_bathymetry=0, R0=1027.0, S0=35.0, T0=14.0,
+                      Tcoef=1.7e-4, Scoef=0.0, rho0=1025.0, tcline=25.0, use_coriolis=1, coriolis_f0=-8.26e-5, coriolis_beta=0.0),
+    # Tests/test_files/Seamount/Seamount.i
+    "Seamount": dict(_DEFAULTS, prob="Seamount", ncell=(49, 48, 13), prob_lo=(0., 0., -5000.), prob_hi=(320000., 320000., 0.),
+                     periodic=(1, 1), fixed_dt=60.0, ndtfast=20, flat_bathymetry=0, use_coriolis=1, coriolis_f0=1.0e-4,
+                     theta_s=6.5, theta_b=2.0, tcline=100.0, R0=1027.0, S0=32.0, T0=10.0, Tcoef=1.7e-4, Scoef=0.0, rho0=1025.0),
+    # Tests/test_files/DoubleGyre/DoubleGyre.i
+    "DoubleGyre": dict(_DEFAULTS, prob="DoubleGyre", ncell=(54, 108, 4), prob_lo=(0., 0., -500.), prob_hi=(1000000., 2000000., 0.),
+                       periodic=(0, 0), fixed_dt=3600.0, ndtfast=20, flat_bathymetry=0, rdrag=8.0e-7, theta_s=0.0, theta_b=0.0,
+                       tcline=1e16, hmix_constant=1, visc2=1280.0, tnu2=(1280.0, 1280.0, 1280.0), R0=1028.0, S0=35.0, T0=5.0,
+                       Tcoef=1.0e-4, Scoef=7.6e-4, rho0=1025.0, use_coriolis=1, coriolis_f0=7.3e-5, coriolis_beta=2.0e-11),
+    # Tests/test_files/Advection/Advection.i
+    "Advection": dict(_DEFAULTS, prob="Advection", ncell=(81, 81, 16), prob_lo=(0., 0., -150.), prob_hi=(41000., 41000., 0.),
+                      periodic=(1, 1), fixed_dt=300.0, ndtfast=30, use_coriolis=0, flat_bathymetry=1, R0=1027.0, S0=35.0,
+                      T0=14.0, Tcoef=1.7e-4, Scoef=0.0, rho0=1025.0, u_0=1.0e-1, v_0=-1.0e-1),
+}
+
+
+def get(name):
+    return copy.deepcopy(CASES[name])
+
+
+def scaled(name, ncell, dt=None):
+    """Same physics and physical domain on a finer grid: prob_hi is kept, so dx
+    shrinks; dt is scaled with the horizontal refinement unless given."""
+    c = get(name)
+    base = c["ncell"]
+    if dt is None:
+        dt = c["fixed_dt"] * min(base[0] / ncell[0], base[1] / ncell[1])
+    c["ncell"] = tuple(ncell)
+    c["fixed_dt"] = float(dt)
+    return c
