@@ -1,0 +1,188 @@
+/*
+ * remora_hip.h -- C ABI of the MI355X-native replacement for REMORA's TimeIntegration hot path.
+ *
+ * REMORA has no plugin/FFI layer; the boundary this library slots into is the C++ member-function
+ * surface of `class REMORA` (Source/REMORA.H:357-648).  Every entry point below names the member
+ * function (file:line in the reference tree) whose body it replaces.  Conventions:
+ *   - all pointers are DEVICE pointers (hipMalloc / AMReX The_Arena on a HIP build), borrowed, never freed here;
+ *   - rh_array4 is amrex::Array4<Real>: p addresses element (lo[0],lo[1],lo[2],comp 0),
+ *       index(i,j,k,n) = (i-lo0) + (j-lo1)*nx + (k-lo2)*nx*ny + n*nx*ny*nz,  nx = hi0-lo0+1, ...
+ *     so MultiFab::array(mfi) maps 1:1 (lo/hi = grown FAB box, global index space);
+ *   - arrays are updated in place exactly where the reference updates them;
+ *   - return value 0 = ok; non-zero = error (rh_last_error() gives the text); the AMReX-side wrapper
+ *     maps non-zero to amrex::Abort, the reference's only error channel (e.g. REMORA_rhs_t_3d.cpp:143);
+ *   - work is enqueued on the stream given to rh_create (NULL = default stream); calls do not synchronise
+ *     unless stated.
+ * FP64 throughout, like the reference (CMakeLists.txt:17).
+ */
+#ifndef REMORA_HIP_H
+#define REMORA_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RH_NCONS 3      /* Source/REMORA_IndexDefines.H:8-11 */
+#define RH_NGROW 2      /* Source/REMORA_IndexDefines.H:13 */
+
+typedef struct { double *p; int lo[3]; int hi[3]; int ncomp; } rh_array4;
+typedef struct { int lo[3]; int hi[3]; } rh_box;
+
+/* mathematical boundary types, Source/REMORA_IndexDefines.H:61-73 (only these three are implemented on device) */
+enum { RH_BC_INT_DIR = 0, RH_BC_FOEXTRAP = 2, RH_BC_EXT_DIR = 3 };
+/* BCVars, Source/REMORA_IndexDefines.H:15-34 */
+enum { RH_BCV_CONS = 0, RH_BCV_XVEL = 3, RH_BCV_YVEL, RH_BCV_ZVEL, RH_BCV_UBAR, RH_BCV_VBAR, RH_BCV_ZETA, RH_BCV_TKE,
+       RH_BCV_FOEXTRAP_PERIODIC, RH_BCV_FOEXTRAP, RH_BCV_U2D_SIMPLE, RH_BCV_V2D_SIMPLE, RH_BCV_NUM };
+/* analytic vertical mixing profiles = the init_custom_vmix hooks of Exec/<case>/prob.cpp that set_analytical_vmix
+ * (Source/REMORA.cpp:565-573) calls from setup_step every step */
+enum { RH_VMIX_CONST = 0, RH_VMIX_UPWELLING = 1 };
+/* analytic surface momentum flux = init_custom_smflux hooks called by set_smflux (Source/REMORA.cpp:598-605) */
+enum { RH_SMFLUX_NONE = 0, RH_SMFLUX_UPWELLING = 1, RH_SMFLUX_FIXED = 2 };
+
+/* Hidden inputs of the reference's member functions: geom[0] (domain, periodicity), solverChoice
+ * (Source/REMORA_DataStruct.H:351-483), fixed_ndtfast_ratio, and the process grid of this rank. */
+typedef struct rh_params {
+    int    domain_lo[3], domain_hi[3];   /* cell-centred domain box, geom[0].Domain() */
+    int    periodic[2];                  /* geometry.is_periodic (x,y) */
+    int    box_lo[3], box_hi[3];         /* this rank's valid cell box (full vertical extent) */
+    int    nranks[2], rank_xy[2];        /* i-j process grid and this rank's coordinates in it */
+    double prob_lo[3], prob_hi[3];
+    double dt;                           /* remora.fixed_dt */
+    int    ndtfast;                      /* remora.fixed_ndtfast_ratio */
+    int    flat_bathymetry, tracer_c4, uv_c2, use_coriolis, use_prestep, use_uv3dmix, use_barotropic, use_salt;
+    double g, rho0, R0, T0, S0, Tcoef, Scoef, theta_s, theta_b, tcline;
+    int    vmix_mode;  double Akv_const, Akt_const[RH_NCONS];
+    int    smflux_mode;
+    int    masks_all_one;                /* 1: land/sea masks are identically 1 (all pinned cases); skips the final cons*=mskr pass */
+} rh_params;
+
+/* One view per MultiFab the reference's drivers touch (Source/REMORA.H:189-354; shapes and ghost widths:
+ * Source/Initialization/REMORA_make_new_level.cpp:259-282,381-389,426-503).  z ghost cells are optional. */
+typedef struct rh_state {
+    rh_array4 cons_old, cons_new, xvel_old, xvel_new, yvel_old, yvel_new, zvel_old, zvel_new;
+    rh_array4 Zt_avg1, h, ubar, vbar, ru, rv, ru2d, rv2d;
+    rh_array4 mskr, msku, mskv, mskp;
+    rh_array4 z_w, z_r, Hz, Huon, Hvom, Akv, Akt, visc2_p, visc2_r, diff2;
+    rh_array4 rufrc, rvfrc, sustr, svstr, rdrag, bustr, bvstr, DU_avg1, DU_avg2, DV_avg1, DV_avg2;
+    rh_array4 rubar, rvbar, rzeta, zeta, pm, pn, fcor, sstore, rhoS, rhoA, bvf;
+} rh_state;
+
+typedef struct rh_ctx rh_ctx;
+
+const char *rh_last_error(void);
+
+/* ---- context ------------------------------------------------------------------------------------- */
+/* Builds the context: BC table (REMORA::init_bcs, Initialization/REMORA_init_bcs.cpp:9-679, SlipWall/periodic subset),
+ * barotropic filter weights (REMORA::set_weights, TimeIntegration/REMORA_set_weights.cpp:10-171), stretching curves
+ * (k-only part of Utils/REMORA_DepthStretchTransform.H:81-139) and device work space.  stream: hipStream_t or NULL. */
+int  rh_create(const rh_params *prm, void *stream, rh_ctx **out);
+int  rh_destroy(rh_ctx *ctx);
+int  rh_nfast(const rh_ctx *ctx);                                  /* REMORA::nfast (REMORA.H:937) */
+int  rh_weights(const rh_ctx *ctx, double *w1, double *w2);        /* vec_weight1/2, 2*ndtfast+1 values each (host) */
+int  rh_sync(rh_ctx *ctx);                                         /* hipStreamSynchronize on the context's stream */
+
+/* Bytes of device memory a native rh_state for this rank needs, and binding of views into such a block
+ * (replaces the MultiFab allocations of make_new_level.cpp:259-282,426-503 when the caller is not AMReX). */
+long rh_state_bytes(const rh_ctx *ctx);
+int  rh_state_bind(const rh_ctx *ctx, void *device_base, rh_state *out);
+
+/* Optional RCCL communicator for i-j decomposed runs: rank 0 calls rh_comm_unique_id, the caller broadcasts the
+ * 128 bytes (e.g. torch.distributed), every rank calls rh_comm_init.  Replaces the MPI side of FillBoundary. */
+int  rh_comm_unique_id(void *id128);
+int  rh_comm_init(rh_ctx *ctx, const void *id128, int rank, int nranks);
+
+/* ---- ghost cells ----------------------------------------------------------------------------------- */
+/* amrex::FabArray::FillBoundary(periodicity) for comps [icomp,icomp+ncomp): periodic wrap and, across ranks,
+ * neighbour exchange (call sites: SURVEY.md section 2.4).  valid = a's box shrunk by ng. */
+int  rh_fill_boundary(rh_ctx *ctx, rh_array4 a, const int ng[3], int icomp, int ncomp);
+/* REMORAPhysBCFunct::operator() (BoundaryConditions/REMORA_PhysBCFunct.cpp:21-93) for int_dir/foextrap/ext_dir sides */
+int  rh_physbc(rh_ctx *ctx, rh_array4 a, const int ng[3], rh_array4 msk, int icomp, int ncomp, int bccomp);
+/* REMORA::FillPatch at level 0 (BoundaryConditions/REMORA_FillPatch.cpp:16-155) = rh_fill_boundary + rh_physbc */
+int  rh_fill_patch(rh_ctx *ctx, rh_array4 a, const int ng[3], rh_array4 msk, int bccomp, int icomp, int ncomp);
+
+/* ---- leaves (Box/Array4 level, Source/REMORA.H:454-648) -------------------------------------------- */
+/* REMORA::stretch_transform, Utils/REMORA_DepthStretchTransform.H:12-249 (z_w, z_r, Hz, h comp 1 from h, Zt_avg1) */
+int  rh_stretch_transform(rh_ctx *ctx, rh_state *s);
+/* REMORA::rho_eos, TimeIntegration/REMORA_rho_eos.cpp:22-99 */
+int  rh_rho_eos(rh_ctx *ctx, rh_box bx, rh_array4 state, rh_array4 rho, rh_array4 rhoA, rh_array4 rhoS, rh_array4 bvf,
+                rh_array4 Hz, rh_array4 z_w, rh_array4 z_r, rh_array4 h, rh_array4 mskr, int N);
+/* REMORA::prsgrd, TimeIntegration/REMORA_prsgrd.cpp:6-197 (P: caller scratch on phi_bx) */
+int  rh_prsgrd(rh_ctx *ctx, rh_box phi_bx, rh_box utbx, rh_box vtbx, rh_array4 ru, rh_array4 rv, rh_array4 pn, rh_array4 pm,
+               rh_array4 rho, rh_array4 P, rh_array4 Hz, rh_array4 z_r, rh_array4 z_w, rh_array4 msku, rh_array4 mskv,
+               int nrhs, int N);
+/* omega: TimeIntegration/REMORA_prestep_t_advection.cpp:97-125 == REMORA_advance_3d.cpp:272-293 */
+int  rh_omega(rh_ctx *ctx, rh_box gbx1, rh_array4 W, rh_array4 Huon, rh_array4 Hvom, rh_array4 z_w, rh_array4 h, int N);
+/* REMORA::prestep_t_advection (REMORA_prestep_t_advection.cpp:127-361, after omega) fused with the tracer call of
+ * REMORA::prestep_diffusion (REMORA_prestep_diffusion.cpp:19-165, lambda = 1): tempstore and t_new for ONE tracer. */
+int  rh_prestep_t(rh_ctx *ctx, rh_box tbx, rh_array4 told, rh_array4 tnew, rh_array4 tempstore, rh_array4 Hz,
+                  rh_array4 Huon, rh_array4 Hvom, rh_array4 W, rh_array4 pm, rh_array4 pn, rh_array4 msku, rh_array4 mskv,
+                  int iic, int ntfirst, int N, double dt);
+/* REMORA::prestep_diffusion for u (ioff=1) or v (joff=1), REMORA_prestep_diffusion.cpp:19-165 */
+int  rh_prestep_uv(rh_ctx *ctx, rh_box vel_bx, int ioff, int joff, rh_array4 vel, rh_array4 vel_old, rh_array4 rvel,
+                   rh_array4 Hz, rh_array4 sstr, rh_array4 bstr, rh_array4 pm, rh_array4 pn,
+                   int iic, int ntfirst, int nrhs, int N, double dt);
+/* REMORA::t3dmix, TimeIntegration/REMORA_t3dmix.cpp:6-58 */
+int  rh_t3dmix(rh_ctx *ctx, rh_box bx, rh_array4 state, rh_array4 state_rhs, rh_array4 diff2, rh_array4 Hz, rh_array4 pm,
+               rh_array4 pn, rh_array4 msku, rh_array4 mskv, double dt, int ncomp);
+/* REMORA::coriolis + REMORA::rhs_uv_3d, TimeIntegration/REMORA_coriolis.cpp:10-40, REMORA_rhs_uv_3d.cpp:31-385 */
+int  rh_rhs_uv_3d(rh_ctx *ctx, rh_box xbx, rh_box ybx, rh_array4 uold, rh_array4 vold, rh_array4 ru, rh_array4 rv,
+                  rh_array4 rufrc, rh_array4 rvfrc, rh_array4 sustr, rh_array4 svstr, rh_array4 bustr, rh_array4 bvstr,
+                  rh_array4 Huon, rh_array4 Hvom, rh_array4 pm, rh_array4 pn, rh_array4 W, rh_array4 Hz, rh_array4 fcor,
+                  int use_coriolis, int nrhs, int N);
+/* REMORA::uv3dmix (3-D call), TimeIntegration/REMORA_uv3dmix.cpp:6-149 */
+int  rh_uv3dmix(rh_ctx *ctx, rh_box xbx, rh_box ybx, rh_array4 u, rh_array4 v, rh_array4 uold, rh_array4 vold,
+                rh_array4 rufrc, rh_array4 rvfrc, rh_array4 visc2_p, rh_array4 visc2_r, rh_array4 Hz, rh_array4 pm,
+                rh_array4 pn, rh_array4 mskp, int nrhs, int nnew, double dt);
+/* REMORA::vert_visc_3d, TimeIntegration/REMORA_vert_visc_3d.cpp:10-107 (no Hzk/AK/BC/DC/FC/CF scratch arguments:
+ * the solve lives in registers / thread-private memory) */
+int  rh_vert_visc_3d(rh_ctx *ctx, rh_box phi_bx, int ioff, int joff, rh_array4 phi, rh_array4 Hz, rh_array4 Akv,
+                     int N, double dt);
+/* REMORA::vert_mean_3d, TimeIntegration/REMORA_vert_mean_3d.cpp:10-47 */
+int  rh_vert_mean_3d(rh_ctx *ctx, rh_box phi_bx, int ioff, int joff, rh_array4 phi, rh_array4 Hz, rh_array4 Dphi_avg1,
+                     rh_array4 dxlen, rh_array4 msk, int N);
+/* REMORA::update_massflux_3d, TimeIntegration/REMORA_update_massflux_3d.cpp:24-122 */
+int  rh_update_massflux_3d(rh_ctx *ctx, rh_box bx, int ioff, int joff, rh_array4 phi, rh_array4 phibar, rh_array4 Hphi,
+                           rh_array4 Hz, rh_array4 pm_or_pn, rh_array4 Dphi_avg1, rh_array4 Dphi_avg2, rh_array4 msk, int N);
+/* REMORA::rhs_t_3d, TimeIntegration/REMORA_rhs_t_3d.cpp:27-335 (one tracer) */
+int  rh_rhs_t_3d(rh_ctx *ctx, rh_box bx, rh_array4 t, rh_array4 sstore, rh_array4 Huon, rh_array4 Hvom, rh_array4 Hz,
+                 rh_array4 pn, rh_array4 pm, rh_array4 W, rh_array4 msku, rh_array4 mskv, int N, double dt);
+
+/* REMORA::rhs_uv_2d, TimeIntegration/REMORA_rhs_uv_2d.cpp:20-238 (rhs_ubar, rhs_vbar -= 2-D momentum advection) */
+int  rh_rhs_uv_2d(rh_ctx *ctx, rh_box xbx, rh_box ybx, rh_array4 ubar, rh_array4 vbar, rh_array4 rhs_ubar, rh_array4 rhs_vbar,
+                  rh_array4 DUon, rh_array4 DVom, int krhs);
+
+/* ---- drivers (MultiFab level, Source/REMORA.H:357-451) --------------------------------------------- */
+/* REMORA::setup_step, TimeIntegration/REMORA_setup_step.cpp:7-369 (+ REMORA::prestep, REMORA_prestep.cpp:36-185) */
+int  rh_setup_step(rh_ctx *ctx, rh_state *s, int istep, double t_old);
+/* REMORA::advance_2d, TimeIntegration/REMORA_advance_2d.cpp:41-757 (step2d; includes rhs_uv_2d, REMORA_rhs_uv_2d.cpp:20-238) */
+int  rh_advance_2d(rh_ctx *ctx, rh_state *s, int istep, double dtfast, int predictor_2d_step, int first_2d_step,
+                   int my_iif, int *next_indx1);
+/* REMORA::advance_2d_onestep, TimeIntegration/REMORA_advance_2d_onestep.cpp:6-53 */
+int  rh_advance_2d_onestep(rh_ctx *ctx, rh_state *s, int istep, int my_iif);
+/* REMORA::advance_3d_ml + REMORA::advance_3d, TimeIntegration/REMORA_advance_3d_ml.cpp:6-71, REMORA_advance_3d.cpp:10-387 */
+int  rh_advance_3d_ml(rh_ctx *ctx, rh_state *s, int istep);
+/* REMORA::Advance, TimeIntegration/REMORA_Advance.cpp:7-35.  The caller swaps old/new first, as REMORA::timeStep does
+ * (TimeIntegration/REMORA_TimeStep.cpp:58-61): rh_swap_old_new does that on the views. */
+int  rh_advance(rh_ctx *ctx, rh_state *s, int istep, double t_old);
+void rh_swap_old_new(rh_state *s);
+
+/* ---- synthetic initial state (outside the hot path; what InitData / prob.cpp provide in REMORA) ---- */
+/* Fills a bound native state for one of the pinned problems (0 Upwelling, 1 Seamount, 2 DoubleGyre, 3 Advection):
+ * Source/REMORA.cpp:246-342,608-702, Initialization/REMORA_init.cpp, Exec/<case>/prob.cpp.  Synchronises. */
+typedef struct rh_init_params {
+    int prob; double rdrag, coriolis_f0, coriolis_beta; int hmix_constant; double visc2, tnu2[RH_NCONS]; double u_0, v_0;
+} rh_init_params;
+int  rh_init_state(rh_ctx *ctx, rh_state *s, const rh_init_params *ip);
+/* plotfile variables of IO/REMORA_Plotfile.cpp:185-235 on the valid box: temp, salt, [scalar], cell-centred u, v, w
+ * (device output buffer, FAB order) */
+int  rh_plot_vars(rh_ctx *ctx, rh_state *s, int with_scalar, double *out_device);
+
+/* per-kernel timing: HIP events recorded on the context's stream around every launch of the named kernel group */
+int  rh_timing_enable(rh_ctx *ctx, int on);
+int  rh_timing_report(rh_ctx *ctx, char *buf, int buflen);        /* JSON: {"kernel":{"calls":n,"ms":t},...}; synchronises */
+int  rh_timing_reset(rh_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,333 @@
+// rh_adv3d.hip -- device kernels of the corrector half of the baroclinic step (REMORA::advance_3d and its leaves).
+// Same mapping as rh_setup.hip: one thread per (i,j) column, i along the wavefront, k marched in registers.
+#include "rh_common.h"
+
+// tracer flux helpers (defined in rh_setup.hip; repeated here as the kernels are compiled per translation unit)
+__device__ __forceinline__ double a3_tflux_u3(double t2, double t1, double t0, double tp, double m1, double m0, double mp, double H, double sgn)
+{
+    const double g1 = (t1 - t2) * m1, g0 = (t0 - t1) * m0, gp = (tp - t0) * mp;
+    const double curv0 = -g0 + gp, curv1 = -g1 + g0;
+    const double maxH = dmax_(H, 0.0), minH = dmin_(H, 0.0);
+    const double a = H * 0.5 * (t0 + t1), b = (1.0 / 6.0) * (curv0 * minH + curv1 * maxH);
+    return sgn < 0.0 ? a - b : a + b;
+}
+__device__ __forceinline__ double a3_tflux_c4(double t2, double t1, double t0, double tp, double m1, double m0, double mp, double H, int mode)
+{
+    const double g1 = (t1 - t2) * m1, g0 = (t0 - t1) * m0, gp = (tp - t0) * mp;
+    const double grad0 = 0.5 * (g0 + gp), grad1 = 0.5 * (g1 + g0);
+    const double cffb = 1.0 / 3.0;
+    return mode == 0 ? H * 0.5 * (t0 + t1 - cffb * (grad0 - grad1)) : H * 0.5 * (t0 + t1) + cffb * (grad0 + grad1);
+}
+__device__ __forceinline__ double a3_tflux_w(const A4 &t, int i, int j, int kk, int N, double w)
+{
+    const double c1 = 0.5, c2 = 7.0 / 12.0, c3 = 1.0 / 12.0;
+    if (kk >= 2 && kk <= N - 1) return (c2 * (t(i, j, kk - 1) + t(i, j, kk)) - c3 * (t(i, j, kk - 2) + t(i, j, kk + 1))) * w;
+    if (kk == N + 1) return 0.0;
+    if (kk == N) return (c2 * t(i, j, N - 1) + c1 * t(i, j, N) - c3 * t(i, j, N - 2)) * w;
+    if (kk == 1) return (c2 * t(i, j, 1) + c1 * t(i, j, 0) - c3 * t(i, j, 2)) * w;
+    return 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REMORA::stretch_transform, Utils/REMORA_DepthStretchTransform.H:12-249 (Vtransform 2): z_w, z_r, Hz and h comp 1 from h
+// and Zt_avg1.  The stretching curves sc/Cs depend on k alone and come from the table built in rh_create; the
+// reference evaluates cosh/exp at every (i,j,k).  sc = [sc_w | Cs_w | sc_r | Cs_r], each nz+1 long.
+__global__ void k_stretch(B3 b, A4 z_w, A4 z_r, A4 Hz, A4 h, A4 Zt, const double *__restrict__ sc, int nz, double hc)
+{
+    RH_IJ(b); if (!inb2(b, i, j)) return;
+    const double *sc_w = sc, *Cs_w = sc + (nz + 1), *sc_r = sc + 2 * (nz + 1), *Cs_r = sc + 3 * (nz + 1);
+    const double hwater = h(i, j, 0, 0);
+    const double hinv = 1.0 / (hc + hwater);
+    const double zt = Zt(i, j, 0);
+    double zw_prev = 0.0;
+    for (int k = 0; k <= nz; k++) {
+        const double cff_w = hc * sc_w[k], cff1_w = Cs_w[k];
+        const double cff2_w = (cff_w + cff1_w * hwater) * hinv;
+        double zw;
+        if (k == nz) zw = zt;
+        else zw = zt + (zt + hwater) * cff2_w;
+        if (k == 0) h(i, j, 0, 1) = zw;
+        z_w(i, j, k) = zw;
+        if (k != nz) {
+            const double cff_r = hc * sc_r[k], cff1_r = Cs_r[k];
+            const double cff2_r = (cff_r + cff1_r * hwater) * hinv;
+            z_r(i, j, k) = zt + (zt + hwater) * cff2_r;
+        }
+        if (k > 0) Hz(i, j, k - 1) = zw - zw_prev;
+        zw_prev = zw;
+    }
+}
+extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
+{
+    TScope t(c, "stretch_transform");
+    const int nz = c->nz;
+    rh_box b = bx_grow(c->bx, 3, 3, 0); b.lo[2] = 0; b.hi[2] = nz - 1;
+    rh_box bw = b; bw.hi[2] = nz;
+    const rh_box b2 = bx_slab(b, 2, 0);
+    RH_NEED(s->z_w, bw); RH_NEED(s->z_r, b); RH_NEED(s->Hz, b); RH_NEED(s->h, b2); RH_NEED(s->Zt_avg1, b2);
+    if (s->h.ncomp < 2) return rh_fail("rh_stretch_transform: h needs 2 components");
+    const double hc = -std::min(c->prm.prob_hi[2], -c->prm.tcline);                          // :51
+    k_stretch<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(s->z_w), mkA(s->z_r), mkA(s->Hz), mkA(s->h), mkA(s->Zt_avg1), c->d_sc, nz, hc);
+    RH_LAUNCH_CHECK();
+    RH_TRY(halo_fill_boundary(c, mfv(c, s->z_w, 0, 0, 1), 0, 1));                            // :198-201
+    RH_TRY(halo_fill_boundary(c, mfv(c, s->z_r, 0, 0, 0), 0, 1));
+    RH_TRY(halo_fill_boundary(c, mfv(c, s->Hz, 0, 0, 0), 0, 1));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// u, v Adams-Bashforth update with the 3-D right-hand side, REMORA_advance_3d.cpp:104-123
+__global__ void k_uv_ab3(B3 xb, B3 yb, B3 un, A4 u, A4 v, A4 ru, A4 rv, A4 Hz, A4 pm, A4 pn, int nrhs, double cff)
+{
+    RH_IJ(un);
+    const int k = un.lo2 + (int)blockIdx.z;
+    if (inb2(xb, i, j)) {
+        double x = u(i, j, k);
+        x += cff * (pm(i, j, 0) + pm(i - 1, j, 0)) * (pn(i, j, 0) + pn(i - 1, j, 0)) * ru(i, j, k, nrhs);
+        x *= 2.0 / (Hz(i - 1, j, k) + Hz(i, j, k));
+        u(i, j, k) = x;
+    }
+    if (inb2(yb, i, j)) {
+        double x = v(i, j, k);
+        x += cff * (pm(i, j, 0) + pm(i, j - 1, 0)) * (pn(i, j, 0) + pn(i, j - 1, 0)) * rv(i, j, k, nrhs);
+        x *= 2.0 / (Hz(i, j - 1, k) + Hz(i, j, k));
+        v(i, j, k) = x;
+    }
+}
+int launch_uv_ab3(rh_ctx *c, rh_state *s, int istep)
+{
+    TScope t(c, "uv_ab3");
+    const rh_box xbx = bx_nodal(c->bx, 0), ybx = bx_nodal(c->bx, 1), un = bx_union(xbx, ybx);
+    const double dt = c->prm.dt;
+    const int iic = istep, ntfirst = 0;
+    double cff;
+    if (iic == ntfirst) cff = 0.25 * dt; else if (iic == ntfirst + 1) cff = 0.25 * dt * 3.0 / 2.0; else cff = 0.25 * dt * 23.0 / 12.0;
+    RH_NEED(s->xvel_new, xbx); RH_NEED(s->yvel_new, ybx); RH_NEED(s->ru, xbx); RH_NEED(s->rv, ybx);
+    RH_NEED(s->Hz, bx_growlo_i(xbx)); RH_NEED(s->Hz, bx_growlo_j(ybx));
+    RH_NEED(s->pm, bx_slab(bx_growlo_i(xbx), 2, 0)); RH_NEED(s->pn, bx_slab(bx_growlo_i(xbx), 2, 0));
+    RH_NEED(s->pm, bx_slab(bx_growlo_j(ybx), 2, 0)); RH_NEED(s->pn, bx_slab(bx_growlo_j(ybx), 2, 0));
+    k_uv_ab3<<<grid3(un), rh_block(), 0, c->stream>>>(mkB(xbx), mkB(ybx), mkB(un), mkA(s->xvel_new), mkA(s->yvel_new), mkA(s->ru), mkA(s->rv),
+        mkA(s->Hz), mkA(s->pm), mkA(s->pn), 0, cff);
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REMORA::vert_visc_3d, REMORA_vert_visc_3d.cpp:10-107: implicit vertical viscosity / diffusion (parabolic-spline
+// tridiagonal system on the k-faces 1..N), one thread per column: upward elimination, downward back-substitution
+// fused with the final update.  Of the reference's six scratch arrays (Hzk, AK, BC, DC, FC, CF) only the two the
+// back-substitution needs (CF, DC) are kept, in a work-space slab laid out like the field ([k][j][i], coalesced).
+__global__ void k_vert_visc(B3 bx, int ioff, int joff, A4 phi, A4 Hz, A4 Akv, A4 wCF, A4 wDC, int N, double dt)
+{
+    RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const int ii = i - ioff, jj = j - joff;
+    const double sixth = 1.0 / 6.0, third = 1.0 / 3.0;
+    double Hzk_m = 0.5 * (Hz(ii, jj, 0) + Hz(i, j, 0));
+    double AK_m = 0.5 * (Akv(ii, jj, 0) + Akv(i, j, 0));
+    double AK_0 = 0.5 * (Akv(ii, jj, 1) + Akv(i, j, 1));
+    double phi_m = phi(i, j, 0);
+    double CFp = 0.0, DCp = 0.0;
+    for (int k = 1; k <= N; k++) {
+        const double Hzk_0 = 0.5 * (Hz(ii, jj, k) + Hz(i, j, k));
+        const double AK_p = 0.5 * (Akv(ii, jj, k + 1) + Akv(i, j, k + 1));
+        const double phi_0 = phi(i, j, k);
+        const double oHzkm1 = 1.0 / Hzk_m;
+        const double oHz = 1.0 / Hzk_0;
+        const double FC = sixth * Hzk_m - dt * AK_m / Hzk_m;
+        double CF = sixth * Hzk_0 - dt * AK_p / Hzk_0;
+        const double BC = third * (Hzk_m + Hzk_0) + dt * AK_0 * (oHzkm1 + oHz);
+        const double cff = 1.0 / (BC - FC * CFp);
+        CF *= cff;
+        const double DC = cff * (phi_0 - phi_m - FC * DCp);
+        wCF(i, j, k) = CF; wDC(i, j, k) = DC;
+        CFp = CF; DCp = DC; Hzk_m = Hzk_0; AK_m = AK_0; AK_0 = AK_p; phi_m = phi_0;
+    }
+    // here AK_0 = AK(N+1), Hzk_m = Hzk(N)
+    double DC_up = 0.0;                 // DC(k+1) of the back-substitution (before the AK scaling)
+    double DCs_up = DC_up * AK_0;       // DC(N+1)*AK(N+1), :96-99
+    for (int k = N; k >= 0; k--) {
+        double DC, AKk;
+        if (k >= 1) { DC = wDC(i, j, k); DC -= wCF(i, j, k) * DC_up; }
+        else DC = 0.0;
+        AKk = 0.5 * (Akv(ii, jj, k) + Akv(i, j, k));
+        const double DCs = DC * AKk;
+        const double Hzk = 0.5 * (Hz(ii, jj, k) + Hz(i, j, k));
+        const double oHz = 1.0 / Hzk;
+        const double cff = dt * oHz * (DCs_up - DCs);
+        phi(i, j, k) += cff;
+        DC_up = DC; DCs_up = DCs;
+    }
+}
+extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 phi, rh_array4 Hz, rh_array4 Akv, int N, double dt)
+{
+    TScope t(c, "vert_visc_3d");
+    if ((ioff != 0 && ioff != 1) || (joff != 0 && joff != 1) || (ioff && joff)) return rh_fail("rh_vert_visc_3d: bad (ioff,joff)");
+    phi_bx.lo[2] = 0; phi_bx.hi[2] = N;
+    rh_box bs = phi_bx; bs.lo[0] -= ioff; bs.lo[1] -= joff;
+    rh_box bw = bs; bw.hi[2] = N + 1;
+    rh_box pw = phi_bx; pw.hi[2] = N + 1;
+    RH_NEED(phi, phi_bx); RH_NEED(Hz, bs); RH_NEED(Akv, bw); RH_NEED(c->wCF, pw); RH_NEED(c->wDC, pw);
+    k_vert_visc<<<grid2(phi_bx), rh_block(), 0, c->stream>>>(mkB(phi_bx), ioff, joff, mkA(phi), mkA(Hz), mkA(Akv), mkA(c->wCF), mkA(c->wDC), N, dt);
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REMORA::vert_mean_3d, REMORA_vert_mean_3d.cpp:10-47: replace the depth mean of u (v) by the barotropic DU_avg1 (DV_avg1)
+__global__ void k_vert_mean(B3 bx, int ioff, int joff, A4 phi, A4 Hz, A4 Davg1, A4 dxlen, A4 msk, int N)
+{
+    RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const int ii = i - ioff, jj = j - joff;
+    double Hzf = 0.5 * (Hz(ii, jj, 0) + Hz(i, j, 0));
+    double CF = Hzf;
+    double DC = phi(i, j, 0) * Hzf;
+    for (int k = 1; k <= N; k++) {
+        Hzf = 0.5 * (Hz(ii, jj, k) + Hz(i, j, k));
+        CF += Hzf;
+        DC += phi(i, j, k) * Hzf;
+    }
+    const double on = 2.0 / (dxlen(ii, jj, 0) + dxlen(i, j, 0));
+    const double cff1 = 1.0 / (CF * (on));
+    DC = (DC * (on) - Davg1(i, j, 0)) * cff1;
+    const double m = msk(i, j, 0);
+    for (int k = 0; k <= N; k++) {
+        double x = phi(i, j, k);
+        x -= DC; x *= m;
+        phi(i, j, k) = x;
+    }
+}
+extern "C" int rh_vert_mean_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 phi, rh_array4 Hz, rh_array4 Dphi_avg1,
+                               rh_array4 dxlen, rh_array4 msk, int N)
+{
+    TScope t(c, "vert_mean_3d");
+    if ((ioff != 0 && ioff != 1) || (joff != 0 && joff != 1) || (ioff && joff)) return rh_fail("rh_vert_mean_3d: bad (ioff,joff)");
+    phi_bx.lo[2] = 0; phi_bx.hi[2] = N;
+    rh_box bs = phi_bx; bs.lo[0] -= ioff; bs.lo[1] -= joff;
+    const rh_box b2 = bx_slab(phi_bx, 2, 0);
+    RH_NEED(phi, phi_bx); RH_NEED(Hz, bs); RH_NEED(Dphi_avg1, b2); RH_NEED(dxlen, bx_slab(bs, 2, 0)); RH_NEED(msk, b2);
+    k_vert_mean<<<grid2(phi_bx), rh_block(), 0, c->stream>>>(mkB(phi_bx), ioff, joff, mkA(phi), mkA(Hz), mkA(Dphi_avg1), mkA(dxlen), mkA(msk), N);
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REMORA::update_massflux_3d, REMORA_update_massflux_3d.cpp:24-122: Huon = 1/2 (Huon + u Hz / n) with its depth integral
+// replaced by DU_avg2, boundary-face velocity correction, ubar comps 0,1.  DC(k) is recomputed instead of stored.
+__global__ void k_massflux(B3 bx, int ioff, int joff, A4 phi, A4 phibar, A4 Hphi, A4 Hz, A4 pmn, A4 Davg1, A4 Davg2, A4 msk,
+                           int N, int dlox, int dhix, int dloy, int dhiy, int perx, int pery)
+{
+    RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const int ii = i - ioff, jj = j - joff;
+    const double on = 2.0 / (pmn(i, j, 0) + pmn(ii, jj, 0));
+    double DCs = 0.0, CF = 0.0;
+    for (int k = 0; k <= N; k++) {
+        const double DCk = 0.5 * on * (Hz(i, j, k) + Hz(ii, jj, k));
+        DCs += DCk;
+        CF += DCk * phi(i, j, k);
+    }
+    const double DCi = 1.0 / DCs;
+    const double a1 = Davg1(i, j, 0);
+    CF = DCi * (CF - a1);
+    const bool edge = (i == dlox - joff && !perx) || (i == dhix + 1 && !perx) || (j == dloy - ioff && !pery) || (j == dhiy + 1 && !pery);
+    if (edge) {
+        const double m = msk(i, j, 0);
+        for (int k = 0; k <= N; k++) { double x = phi(i, j, k); x -= CF; x *= m; phi(i, j, k) = x; }
+    }
+    double FC = 0.0;
+    for (int k = 0; k <= N; k++) {
+        const double DCk = 0.5 * on * (Hz(i, j, k) + Hz(ii, jj, k));
+        const double hp = 0.5 * (Hphi(i, j, k) + phi(i, j, k) * DCk);
+        Hphi(i, j, k) = hp;
+        FC += hp;
+    }
+    FC = DCi * (FC - Davg2(i, j, 0));
+    for (int k = 0; k <= N; k++) {
+        const double DCk = 0.5 * on * (Hz(i, j, k) + Hz(ii, jj, k));
+        Hphi(i, j, k) -= DCk * FC;
+    }
+    const double pb = DCi * a1;
+    phibar(i, j, 0, 0) = pb; phibar(i, j, 0, 1) = pb;
+}
+extern "C" int rh_update_massflux_3d(rh_ctx *c, rh_box bx, int ioff, int joff, rh_array4 phi, rh_array4 phibar, rh_array4 Hphi,
+                                     rh_array4 Hz, rh_array4 pm_or_pn, rh_array4 Dphi_avg1, rh_array4 Dphi_avg2, rh_array4 msk, int N)
+{
+    TScope t(c, "update_massflux_3d");
+    if ((ioff | joff) != 1 || (ioff & joff)) return rh_fail("rh_update_massflux_3d: (ioff,joff) must be (1,0) or (0,1)");
+    bx.lo[2] = 0; bx.hi[2] = N;
+    rh_box bs = bx; bs.lo[0] -= ioff; bs.lo[1] -= joff;
+    const rh_box b2 = bx_slab(bx, 2, 0);
+    if (phibar.ncomp < 2) return rh_fail("rh_update_massflux_3d: phibar needs 2 components");
+    RH_NEED(phi, bx); RH_NEED(Hphi, bx); RH_NEED(Hz, bs); RH_NEED(pm_or_pn, bx_slab(bs, 2, 0));
+    RH_NEED(phibar, b2); RH_NEED(Dphi_avg1, b2); RH_NEED(Dphi_avg2, b2); RH_NEED(msk, b2);
+    k_massflux<<<grid2(bx), rh_block(), 0, c->stream>>>(mkB(bx), ioff, joff, mkA(phi), mkA(phibar), mkA(Hphi), mkA(Hz), mkA(pm_or_pn),
+        mkA(Dphi_avg1), mkA(Dphi_avg2), mkA(msk), N, c->dom.lo[0], c->dom.hi[0], c->dom.lo[1], c->dom.hi[1], c->prm.periodic[0], c->prm.periodic[1]);
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REMORA::rhs_t_3d, REMORA_rhs_t_3d.cpp:27-335: corrector tracer advection with the predictor field sstore, one tracer.
+// Horizontal fluxes (third-order upstream / fourth-order centred, flat-bathymetry sign quirk included), horizontal update,
+// fourth-order vertical flux and division by Hz in one upward sweep; FX/FE/curv/grad/FC never touch memory.
+template <int C4>
+__global__ void k_rhs_t(B3 bx, A4 t, A4 ss, A4 Huon, A4 Hvom, A4 Hz, A4 pn, A4 pm, A4 W, A4 msku, A4 mskv, int N, double dt, int flat)
+{
+    RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const double cff = dt * pm(i, j, 0) * pn(i, j, 0);
+    const double mu1 = msku(i - 1, j, 0), mu0 = msku(i, j, 0), mup = msku(i + 1, j, 0), mupp = msku(i + 2, j, 0);
+    const double mv1 = mskv(i, j - 1, 0), mv0 = mskv(i, j, 0), mvp = mskv(i, j + 1, 0), mvpp = mskv(i, j + 2, 0);
+    const double sgn = flat ? 1.0 : -1.0;
+    double FCk = 0.0;
+    for (int k = 0; k <= N; k++) {
+        const double s0 = ss(i, j, k);
+        const double xm2 = ss(i - 2, j, k), xm1 = ss(i - 1, j, k), xp1 = ss(i + 1, j, k), xp2 = ss(i + 2, j, k);
+        const double ym2 = ss(i, j - 2, k), ym1 = ss(i, j - 1, k), yp1 = ss(i, j + 1, k), yp2 = ss(i, j + 2, k);
+        const double Hu0 = Huon(i, j, k), Hu1 = Huon(i + 1, j, k), Hv0 = Hvom(i, j, k), Hv1 = Hvom(i, j + 1, k);
+        double FX0, FX1, FE0, FE1;
+        if (!C4) {
+            FX0 = a3_tflux_u3(xm2, xm1, s0, xp1, mu1, mu0, mup, Hu0, sgn); FX1 = a3_tflux_u3(xm1, s0, xp1, xp2, mu0, mup, mupp, Hu1, sgn);
+            FE0 = a3_tflux_u3(ym2, ym1, s0, yp1, mv1, mv0, mvp, Hv0, sgn); FE1 = a3_tflux_u3(ym1, s0, yp1, yp2, mv0, mvp, mvpp, Hv1, sgn);
+        } else {
+            FX0 = a3_tflux_c4(xm2, xm1, s0, xp1, mu1, mu0, mup, Hu0, flat); FX1 = a3_tflux_c4(xm1, s0, xp1, xp2, mu0, mup, mupp, Hu1, flat);
+            FE0 = a3_tflux_c4(ym2, ym1, s0, yp1, mv1, mv0, mvp, Hv0, flat); FE1 = a3_tflux_c4(ym1, s0, yp1, yp2, mv0, mvp, mvpp, Hv1, flat);
+        }
+        double x = t(i, j, k);
+        const double cff1 = cff * (FX1 - FX0);
+        const double cff2 = cff * (FE1 - FE0);
+        const double cff3 = cff1 + cff2;
+        x -= cff3;
+        const double FCk1 = a3_tflux_w(ss, i, j, k + 1, N, W(i, j, k + 1));
+        const double cff4 = FCk1 - FCk;
+        t(i, j, k) = (x - cff * cff4) / Hz(i, j, k);
+        FCk = FCk1;
+    }
+}
+extern "C" int rh_rhs_t_3d(rh_ctx *c, rh_box bx, rh_array4 t, rh_array4 sstore, rh_array4 Huon, rh_array4 Hvom, rh_array4 Hz,
+                           rh_array4 pn, rh_array4 pm, rh_array4 W, rh_array4 msku, rh_array4 mskv, int N, double dt)
+{
+    TScope ts(c, "rhs_t_3d");
+    bx.lo[2] = 0; bx.hi[2] = N;
+    const rh_box g2 = bx_grow(bx, 2, 2, 0), b2 = bx_slab(bx, 2, 0);
+    rh_box bw = bx; bw.hi[2] = N + 1;
+    RH_NEED(sstore, g2); RH_NEED(t, bx); RH_NEED(Hz, bx); RH_NEED(W, bw);
+    RH_NEED(Huon, bx_nodal(bx, 0)); RH_NEED(Hvom, bx_nodal(bx, 1)); RH_NEED(pm, b2); RH_NEED(pn, b2);
+    { rh_box m = b2; m.lo[0] -= 1; m.hi[0] += 2; RH_NEED(msku, m); }
+    { rh_box m = b2; m.lo[1] -= 1; m.hi[1] += 2; RH_NEED(mskv, m); }
+#define RH_RT(C4) k_rhs_t<C4><<<grid2(bx), rh_block(), 0, c->stream>>>(mkB(bx), mkA(t), mkA(sstore), mkA(Huon), mkA(Hvom), mkA(Hz), mkA(pn), mkA(pm), \
+        mkA(W), mkA(msku), mkA(mskv), N, dt, c->prm.flat_bathymetry ? 1 : 0)
+    if (c->prm.tracer_c4) RH_RT(1); else RH_RT(0);
+#undef RH_RT
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// cons *= mskr, REMORA_advance_3d_ml.cpp:51-62
+__global__ void k_mask_cons(B3 bx, A4 cons, A4 mskr, int nc)
+{
+    RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const int k = bx.lo2 + (int)blockIdx.z;
+    const double m = mskr(i, j, 0);
+    for (int n = 0; n < nc; n++) cons(i, j, k, n) *= m;
+}
+int launch_mask_cons(rh_ctx *c, rh_state *s)
+{
+    RH_NEED(s->cons_new, c->bx); RH_NEED(s->mskr, bx_slab(c->bx, 2, 0));
+    k_mask_cons<<<grid3(c->bx), rh_block(), 0, c->stream>>>(mkB(c->bx), mkA(s->cons_new), mkA(s->mskr), RH_NCONS);
+    RH_LAUNCH_CHECK(); return 0;
+}

@@ -1,0 +1,127 @@
+// rh_common.h -- shared device/host helpers of the MI355X REMORA hot path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <map>
+#include "../../include/remora_hip.h"
+
+// Device-side view with the amrex::Array4 memory order (i fastest).  Built once per launch on the host.
+struct A4 {
+    double *p; int lo0, lo1, lo2, hi0, hi1, hi2, nc; long sy, sz, sn;
+    __host__ __device__ __forceinline__ long ix(int i, int j, int k) const
+    { return (long)(i - lo0) + (long)(j - lo1) * sy + (long)(k - lo2) * sz; }
+    __device__ __forceinline__ double &operator()(int i, int j, int k) const { return p[ix(i, j, k)]; }
+    __device__ __forceinline__ double &operator()(int i, int j, int k, int n) const { return p[ix(i, j, k) + (long)n * sn]; }
+};
+
+static inline A4 mkA(const rh_array4 &a)
+{
+    A4 r; r.p = a.p; r.lo0 = a.lo[0]; r.lo1 = a.lo[1]; r.lo2 = a.lo[2]; r.hi0 = a.hi[0]; r.hi1 = a.hi[1]; r.hi2 = a.hi[2];
+    r.nc = a.ncomp; r.sy = a.hi[0] - a.lo[0] + 1; r.sz = r.sy * (a.hi[1] - a.lo[1] + 1); r.sn = r.sz * (a.hi[2] - a.lo[2] + 1);
+    return r;
+}
+static inline A4 mkA(const rh_array4 &a, int comp) { A4 r = mkA(a); r.p += r.sn * comp; r.nc -= comp; return r; }
+static inline long a4_size(const rh_array4 &a)
+{ return (long)(a.hi[0]-a.lo[0]+1)*(a.hi[1]-a.lo[1]+1)*(a.hi[2]-a.lo[2]+1)*a.ncomp; }
+static inline rh_array4 a4_comp(rh_array4 a, int comp)
+{ a.p += (long)(a.hi[0]-a.lo[0]+1)*(a.hi[1]-a.lo[1]+1)*(a.hi[2]-a.lo[2]+1)*comp; a.ncomp -= comp; return a; }
+
+struct B3 { int lo0, lo1, lo2, hi0, hi1, hi2; };
+static inline B3 mkB(const rh_box &b) { return B3{b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2]}; }
+static inline rh_box bx_make(int l0,int l1,int l2,int h0,int h1,int h2){ rh_box b={{l0,l1,l2},{h0,h1,h2}}; return b; }
+static inline rh_box bx_grow(rh_box b,int g0,int g1,int g2){ b.lo[0]-=g0;b.hi[0]+=g0;b.lo[1]-=g1;b.hi[1]+=g1;b.lo[2]-=g2;b.hi[2]+=g2; return b; }
+static inline rh_box bx_nodal(rh_box b,int d){ b.hi[d]+=1; return b; }
+static inline rh_box bx_slab(rh_box b,int d,int v){ b.lo[d]=v; b.hi[d]=v; return b; }
+static inline rh_box bx_and(rh_box a, rh_box b){ for(int d=0;d<3;d++){ if(b.lo[d]>a.lo[d])a.lo[d]=b.lo[d]; if(b.hi[d]<a.hi[d])a.hi[d]=b.hi[d]; } return a; }
+static inline rh_box bx_union(rh_box a, rh_box b){ for(int d=0;d<3;d++){ if(b.lo[d]<a.lo[d])a.lo[d]=b.lo[d]; if(b.hi[d]>a.hi[d])a.hi[d]=b.hi[d]; } return a; }
+static inline bool  bx_ok(rh_box b){ return b.lo[0]<=b.hi[0]&&b.lo[1]<=b.hi[1]&&b.lo[2]<=b.hi[2]; }
+static inline rh_box bx_of(const rh_array4 &a){ rh_box b; for(int d=0;d<3;d++){b.lo[d]=a.lo[d];b.hi[d]=a.hi[d];} return b; }
+static inline bool bx_contains(rh_box a, rh_box b){ for(int d=0;d<3;d++) if(b.lo[d]<a.lo[d]||b.hi[d]>a.hi[d]) return false; return true; }
+static inline rh_box bx_growlo_i(rh_box b){ b.lo[0]-=1; return b; }
+static inline rh_box bx_growlo_j(rh_box b){ b.lo[1]-=1; return b; }
+static inline long bx_npts(rh_box b){ return bx_ok(b) ? (long)(b.hi[0]-b.lo[0]+1)*(b.hi[1]-b.lo[1]+1)*(b.hi[2]-b.lo[2]+1) : 0; }
+
+__device__ __forceinline__ bool inb(const B3 &b, int i, int j, int k)
+{ return i >= b.lo0 && i <= b.hi0 && j >= b.lo1 && j <= b.hi1 && k >= b.lo2 && k <= b.hi2; }
+__device__ __forceinline__ bool inb2(const B3 &b, int i, int j)
+{ return i >= b.lo0 && i <= b.hi0 && j >= b.lo1 && j <= b.hi1; }
+
+// std::max / std::min semantics of the reference (first argument on ties)
+__device__ __forceinline__ double dmax_(double a, double b) { return (a < b) ? b : a; }
+__device__ __forceinline__ double dmin_(double a, double b) { return (b < a) ? b : a; }
+
+// Launch geometry.  x threads run along i (coalesced 512-B rows per wave), RH_BY rows of j per block.
+#define RH_BX 64
+#define RH_BY 4
+static inline dim3 rh_block() { return dim3(RH_BX, RH_BY, 1); }
+// pointwise 3-D kernels: grid.z walks k
+static inline dim3 grid3(const rh_box &b)
+{ return dim3((b.hi[0]-b.lo[0]+RH_BX)/RH_BX, (b.hi[1]-b.lo[1]+RH_BY)/RH_BY, b.hi[2]-b.lo[2]+1); }
+// column kernels / 2-D kernels: one thread per (i,j)
+static inline dim3 grid2(const rh_box &b)
+{ return dim3((b.hi[0]-b.lo[0]+RH_BX)/RH_BX, (b.hi[1]-b.lo[1]+RH_BY)/RH_BY, 1); }
+#define RH_IJ(b) const int i = (b).lo0 + (int)(blockIdx.x * RH_BX + threadIdx.x); const int j = (b).lo1 + (int)(blockIdx.y * RH_BY + threadIdx.y)
+
+extern thread_local std::string g_rh_err;
+int rh_fail(const char *fmt, ...);
+#define RH_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return rh_fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+#define RH_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
+#define RH_LAUNCH_CHECK() RH_HIP(hipGetLastError())
+// operand-shape guard used before every launch: the box a kernel indexes must lie inside the array it indexes
+#define RH_NEED(arr, box) do { if (!bx_contains(bx_of(arr), (box))) return rh_fail("%s: array %s [%d:%d,%d:%d,%d:%d] does not cover box [%d:%d,%d:%d,%d:%d] (%s:%d)", __func__, #arr, \
+    (arr).lo[0],(arr).hi[0],(arr).lo[1],(arr).hi[1],(arr).lo[2],(arr).hi[2],(box).lo[0],(box).hi[0],(box).lo[1],(box).hi[1],(box).lo[2],(box).hi[2], __FILE__, __LINE__); } while (0)
+
+struct BCRec3 { int lo[3], hi[3]; };
+
+// a view plus what AMReX keeps in the MultiFab: valid box, index type, ghost widths
+struct MFV { rh_array4 a; rh_box valid; int ix[3]; int ng[3]; };
+
+struct rh_ctx {
+    rh_params prm;
+    hipStream_t stream;
+    int N, nz;
+    rh_box dom, bx;                  // domain and this rank's valid cell box
+    int nfast; std::vector<double> w1, w2;
+    BCRec3 bcs[RH_BCV_NUM]; double extdir[RH_BCV_NUM][6];
+    // stretching curves (host-computed, device copy): [4][nz+1] = sc_w, Cs_w, sc_r, Cs_r
+    std::vector<double> h_sc; double *d_sc = nullptr;
+    // device work space (replaces the per-call MultiFab / FArrayBox temporaries of the reference)
+    rh_array4 rho, P, W, wCF, wDC, DUon, DVom, Drhs, Dnew, zwrk, gzeta, gzeta2, gzetaSA;
+    double *d_work = nullptr; long work_bytes = 0;
+    // RCCL
+    void *comm = nullptr; int rank = 0, nranks = 1;
+    // per-kernel-group timing
+    bool timing = false;
+    std::vector<std::string> tnames; std::map<std::string,int> tslot;
+    std::vector<std::vector<std::pair<hipEvent_t,hipEvent_t>>> tev;
+    std::vector<hipEvent_t> evpool;
+    bool poison = false;             // RH_POISON=1: NaN-fill the work space at the start of every step (stale-read detector)
+};
+
+// timing scope: records events around a kernel group when enabled
+struct TScope {
+    rh_ctx *c; hipEvent_t a, b; int slot; bool on;
+    TScope(rh_ctx *ctx, const char *name);
+    ~TScope();
+};
+
+// ---- internal entry points shared between the .hip files ----
+MFV  mfv(const rh_ctx *c, const rh_array4 &a, int ix0, int ix1, int ix2);
+// halo / bc (rh_halo.hip)
+int  halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp);
+int  halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill);
+int  halo_fillpatch(rh_ctx *c, const MFV &m, const rh_array4 &msk, int bccomp, int icomp, int ncomp);
+// kernels without a C entry point of their own (rh_setup.hip, rh_adv3d.hip, rh_step2d.hip)
+int  launch_bstress(rh_ctx *c, rh_state *s);
+int  launch_massflux_old(rh_ctx *c, rh_state *s);
+int  launch_vmix(rh_ctx *c, rh_state *s);
+int  launch_set_zeta(rh_ctx *c, rh_state *s);
+int  launch_uv_ab3(rh_ctx *c, rh_state *s, int istep);
+int  launch_mask_cons(rh_ctx *c, rh_state *s);
+// small utilities (rh_ctx.hip)
+int  dev_setval(rh_ctx *c, const rh_array4 &a, int icomp, int ncomp, double v);
+int  dev_copy(rh_ctx *c, const rh_array4 &dst, const rh_array4 &src);

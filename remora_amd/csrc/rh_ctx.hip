@@ -1,0 +1,342 @@
+// rh_ctx.hip -- context, BC table, barotropic filter weights, stretching curves, native state layout, timing.
+#include "rh_common.h"
+#include <cstdarg>
+#include <cstdlib>
+
+thread_local std::string g_rh_err;
+
+int rh_fail(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    g_rh_err = buf;
+    return 1;
+}
+extern "C" const char *rh_last_error(void) { return g_rh_err.c_str(); }
+
+// ------------------------------------------------------------------------------------------------ timing
+TScope::TScope(rh_ctx *ctx, const char *name) : c(ctx), on(ctx->timing)
+{
+    if (!on) return;
+    auto it = c->tslot.find(name);
+    if (it == c->tslot.end()) { slot = (int)c->tnames.size(); c->tslot[name] = slot; c->tnames.push_back(name); c->tev.emplace_back(); }
+    else slot = it->second;
+    auto get = [&](hipEvent_t &e) { if (!c->evpool.empty()) { e = c->evpool.back(); c->evpool.pop_back(); } else (void)hipEventCreate(&e); };
+    get(a); get(b);
+    (void)hipEventRecord(a, c->stream);
+}
+TScope::~TScope()
+{
+    if (!on) return;
+    (void)hipEventRecord(b, c->stream);
+    c->tev[slot].push_back({a, b});
+}
+
+extern "C" int rh_timing_enable(rh_ctx *c, int on) { c->timing = on != 0; return 0; }
+extern "C" int rh_timing_reset(rh_ctx *c)
+{
+    RH_HIP(hipStreamSynchronize(c->stream));
+    for (auto &v : c->tev) { for (auto &p : v) { c->evpool.push_back(p.first); c->evpool.push_back(p.second); } v.clear(); }
+    return 0;
+}
+extern "C" int rh_timing_report(rh_ctx *c, char *buf, int buflen)
+{
+    RH_HIP(hipStreamSynchronize(c->stream));
+    std::string s = "{";
+    for (size_t q = 0; q < c->tnames.size(); q++) {
+        double ms = 0; for (auto &p : c->tev[q]) { float t = 0; (void)hipEventElapsedTime(&t, p.first, p.second); ms += t; }
+        char tmp[256]; snprintf(tmp, sizeof tmp, "%s\"%s\":{\"calls\":%zu,\"ms\":%.6f}", q ? "," : "", c->tnames[q].c_str(), c->tev[q].size(), ms);
+        s += tmp;
+    }
+    s += "}";
+    if ((int)s.size() + 1 > buflen) return rh_fail("rh_timing_report: buffer too small (%zu needed)", s.size() + 1);
+    memcpy(buf, s.c_str(), s.size() + 1);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ small device utilities
+__global__ void k_setval(double *p, long n, double v)
+{
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x; const long st = (long)gridDim.x * blockDim.x;
+    for (; q < n; q += st) p[q] = v;
+}
+__global__ void k_copy(double *d, const double *s, long n)
+{
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x; const long st = (long)gridDim.x * blockDim.x;
+    for (; q < n; q += st) d[q] = s[q];
+}
+static inline int nblk(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+int dev_setval(rh_ctx *c, const rh_array4 &a, int icomp, int ncomp, double v)
+{
+    long per = a4_size(a) / a.ncomp; long n = per * ncomp; if (n <= 0) return 0;
+    k_setval<<<nblk(n), 256, 0, c->stream>>>(a.p + per * icomp, n, v);
+    RH_LAUNCH_CHECK(); return 0;
+}
+int dev_copy(rh_ctx *c, const rh_array4 &dst, const rh_array4 &src)
+{
+    if (a4_size(dst) != a4_size(src)) return rh_fail("dev_copy: size mismatch");
+    long n = a4_size(dst); if (n <= 0) return 0;
+    k_copy<<<nblk(n), 256, 0, c->stream>>>(dst.p, src.p, n);
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+MFV mfv(const rh_ctx *c, const rh_array4 &a, int ix0, int ix1, int ix2)
+{
+    MFV m; m.a = a; m.ix[0] = ix0; m.ix[1] = ix1; m.ix[2] = ix2;
+    m.valid = c->bx;
+    // 2-D arrays live on the k = 0 slab; k-limited coefficient arrays keep their own k range
+    m.valid.lo[2] = a.lo[2]; m.valid.hi[2] = a.hi[2];
+    if (ix0) m.valid.hi[0] += 1;
+    if (ix1) m.valid.hi[1] += 1;
+    for (int d = 0; d < 2; d++) m.ng[d] = m.valid.lo[d] - a.lo[d];
+    m.ng[2] = 0;
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------ set_weights
+// REMORA::set_weights, Source/TimeIntegration/REMORA_set_weights.cpp:10-171 (power-law shape filter, host scalar code)
+static int set_weights(int ndtfast, std::vector<double> &weight1, std::vector<double> &weight2)
+{
+    double gamma, scale, wsum, shift, cff;
+    const double Falpha = 2.0, Fbeta = 4.0, Fgamma = 0.284;
+    int nfast = 0;
+    weight1.assign(2 * ndtfast + 1, 0.0); weight2.assign(2 * ndtfast + 1, 0.0);
+    scale = (Falpha + 1.0) * (Falpha + Fbeta + 1.0) / ((Falpha + 2.0) * (Falpha + Fbeta + 2.0) * (double)ndtfast);
+    gamma = Fgamma * std::max(0.0, 1.0 - 10.0 / (double)ndtfast);
+    for (int iter = 1; iter <= 16; iter++) {
+        nfast = 0;
+        for (int i = 1; i <= 2 * ndtfast; i++) {
+            cff = scale * (double)i;
+            weight1[i-1] = (double)(pow(cff, Falpha) - pow(cff, (Falpha + Fbeta))) - gamma * cff;
+            if (weight1[i-1] > 0.0) nfast = i;
+            if ((nfast > 0) && (weight1[i-1] < 0.0)) weight1[i-1] = 0.0;
+        }
+        wsum = 0.0; shift = 0.0;
+        for (int i = 1; i <= nfast; i++) { wsum = wsum + weight1[i-1]; shift = shift + weight1[i-1] * (double)i; }
+        scale *= shift / (wsum * (double)ndtfast);
+    }
+    for (int iter = 1; iter <= ndtfast; iter++) {
+        wsum = 0.0; shift = 0.0;
+        for (int i = 1; i <= nfast; i++) { wsum = wsum + weight1[i-1]; shift = shift + (double)i * weight1[i-1]; }
+        shift = shift / wsum;
+        cff = (double)ndtfast - shift;
+        if (cff > 1.0) {
+            nfast = nfast + 1;
+            for (int i = nfast; i >= 2; i--) weight1[i-1] = weight1[i-2];
+            weight1[0] = 0.0;
+        } else if (cff > 0.0) {
+            wsum = 1.0 - cff;
+            for (int i = nfast; i >= 2; i--) weight1[i-1] = wsum * weight1[i-1] + cff * weight1[i-2];
+            weight1[0] = wsum * weight1[0];
+        } else if (cff < -1.0) {
+            nfast = nfast - 1;
+            for (int i = 1; i <= nfast; i++) weight1[i-1] = weight1[i];
+            weight1[nfast] = 0.0;
+        } else if (cff < 0.0) {
+            wsum = 1.0 + cff;
+            for (int i = 1; i <= nfast - 1; i++) weight1[i-1] = wsum * weight1[i-1] - cff * weight1[i];
+            weight1[nfast-1] = wsum * weight1[nfast-1];
+        }
+    }
+    for (int j = 1; j <= nfast; j++) { cff = weight1[j-1]; for (int i = 1; i <= j; i++) weight2[i-1] = weight2[i-1] + cff; }
+    wsum = 0.0; cff = 0.0;
+    for (int i = 1; i <= nfast; i++) { wsum = wsum + weight1[i-1]; cff = cff + weight2[i-1]; }
+    wsum = 1.0 / wsum; cff = 1.0 / cff;
+    for (int i = 1; i <= nfast; i++) { weight1[i-1] = wsum * weight1[i-1]; weight2[i-1] = cff * weight2[i-1]; }
+    return nfast;
+}
+
+// k-only part of REMORA::stretch_transform, Source/Utils/REMORA_DepthStretchTransform.H:81-139 (N = nz there).
+// The reference evaluates cosh/exp per (i,j,k); the curves depend on k alone, so they are tabulated once.
+static void stretch_coeffs(int k, int N, double theta_s, double theta_b, double *sc_w_o, double *Cs_w_o, double *sc_r_o, double *Cs_r_o)
+{
+    const double ds = 1.0 / (double)N;
+    double Csur, Cbot, sc_r, sc_w, Cs_r, Cs_w;
+    if (k == N) { sc_w = 0.0; Cs_w = 0.0; }
+    else if (k == 0) { sc_w = -1.0; Cs_w = -1.0; }
+    else {
+        sc_w = ds * (k - N);
+        if (theta_s > 0.0) Csur = (1.0 - cosh(theta_s * sc_w)) / (cosh(theta_s) - 1.0);
+        else Csur = -sc_w * sc_w;
+        if (theta_b > 0.0) { Cbot = (exp(theta_b * Csur) - 1.0) / (1.0 - exp(-theta_b)); Cs_w = Cbot; }
+        else Cs_w = Csur;
+    }
+    sc_r = ds * (k - N + 0.5);
+    if (theta_s > 0.0) Csur = (1.0 - cosh(theta_s * sc_r)) / (cosh(theta_s) - 1.0);
+    else Csur = -sc_r * sc_r;
+    if (theta_b > 0.0) { Cbot = (exp(theta_b * Csur) - 1.0) / (1.0 - exp(-theta_b)); Cs_r = Cbot; }
+    else Cs_r = Csur;
+    *sc_w_o = sc_w; *Cs_w_o = Cs_w; *sc_r_o = sc_r; *Cs_r_o = Cs_r;
+}
+
+// REMORA::init_bcs, Source/Initialization/REMORA_init_bcs.cpp:9-679, for the periodic / SlipWall sides the pinned cases use
+static void init_bcs(rh_ctx *c)
+{
+    const int BOGUS = -666;
+    auto setall = [&](int v, int dir, int t) { c->bcs[v].lo[dir] = t; c->bcs[v].hi[dir] = t; };
+    for (int v = 0; v < RH_BCV_NUM; v++) for (int d = 0; d < 3; d++) { c->bcs[v].lo[d] = BOGUS; c->bcs[v].hi[d] = BOGUS; }
+    for (int v = 0; v < RH_BCV_NUM; v++) for (int o = 0; o < 6; o++) c->extdir[v][o] = 0.0;
+    for (int o = 0; o < 6; o++) { c->extdir[0][o] = 1.e19; c->extdir[1][o] = 1.e20; c->extdir[2][o] = 1.e21; }   // :161-163
+    for (int dir = 0; dir < 3; dir++) {
+        const int per = (dir < 2) ? c->prm.periodic[dir] : 0;      // z is always SlipWall (:130)
+        const int base = per ? RH_BC_INT_DIR : RH_BC_FOEXTRAP;
+        setall(RH_BCV_XVEL, dir, base); setall(RH_BCV_YVEL, dir, base);                      // :218-309
+        if (!per && dir < 2) setall(RH_BCV_XVEL + dir, dir, RH_BC_EXT_DIR);
+        setall(RH_BCV_ZVEL, dir, RH_BC_FOEXTRAP);                                            // :311-316
+        for (int n = 0; n < RH_NCONS; n++) setall(RH_BCV_CONS + n, dir, base);               // :331-409
+        setall(RH_BCV_UBAR, dir, base); setall(RH_BCV_VBAR, dir, base);                      // :425-541
+        setall(RH_BCV_U2D_SIMPLE, dir, base); setall(RH_BCV_V2D_SIMPLE, dir, base);
+        if (!per && dir < 2) { setall(RH_BCV_UBAR + dir, dir, RH_BC_EXT_DIR); setall(RH_BCV_U2D_SIMPLE + dir, dir, RH_BC_EXT_DIR); }
+        setall(RH_BCV_ZETA, dir, base); setall(RH_BCV_TKE, dir, base);                       // :556-627
+        setall(RH_BCV_FOEXTRAP_PERIODIC, dir, RH_BC_FOEXTRAP);                               // :636-648
+        setall(RH_BCV_FOEXTRAP, dir, RH_BC_FOEXTRAP);                                        // :655-667
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ native state layout
+// Shapes and ghost widths: Source/Initialization/REMORA_make_new_level.cpp:259-282,381-389,426-503 (NGROW = 2).
+// kind: 0 = 3-D cell/face array over the full column, 1 = 2-D (k = 0 slab), 2 = k-limited coefficient array (k = 0..1:
+// visc2_p / visc2_r / diff2 are 3-D in the reference but only ever indexed at k = 0, and at k = 1 through the
+// 3-index access of REMORA_t3dmix.cpp:34,43)
+struct FieldSpec { rh_array4 rh_state::*m; int ix0, ix1, ix2, nc, ng0, ng1, kind; };
+static const FieldSpec g_fields[] = {
+    {&rh_state::cons_old,0,0,0,RH_NCONS,3,3,0}, {&rh_state::cons_new,0,0,0,RH_NCONS,3,3,0},
+    {&rh_state::xvel_old,1,0,0,1,3,3,0}, {&rh_state::xvel_new,1,0,0,1,3,3,0},
+    {&rh_state::yvel_old,0,1,0,1,3,3,0}, {&rh_state::yvel_new,0,1,0,1,3,3,0},
+    {&rh_state::zvel_old,0,0,1,1,3,3,0}, {&rh_state::zvel_new,0,0,1,1,3,3,0},
+    {&rh_state::Zt_avg1,0,0,0,1,3,3,1}, {&rh_state::h,0,0,0,2,3,3,1},
+    {&rh_state::ubar,1,0,0,3,2,2,1}, {&rh_state::vbar,0,1,0,3,2,2,1},
+    {&rh_state::ru,1,0,0,2,2,2,0}, {&rh_state::rv,0,1,0,2,2,2,0},
+    {&rh_state::ru2d,1,0,0,2,2,2,1}, {&rh_state::rv2d,0,1,0,2,2,2,1},
+    {&rh_state::mskr,0,0,0,1,3,3,1}, {&rh_state::msku,1,0,0,1,3,3,1}, {&rh_state::mskv,0,1,0,1,3,3,1}, {&rh_state::mskp,1,1,0,1,3,3,1},
+    {&rh_state::z_w,0,0,1,1,3,3,0}, {&rh_state::z_r,0,0,0,1,3,3,0}, {&rh_state::Hz,0,0,0,1,3,3,0},
+    {&rh_state::Huon,1,0,0,1,2,2,0}, {&rh_state::Hvom,0,1,0,1,2,2,0},
+    {&rh_state::Akv,0,0,1,1,2,2,0}, {&rh_state::Akt,0,0,1,RH_NCONS,2,2,0},
+    {&rh_state::visc2_p,0,0,0,1,2,2,2}, {&rh_state::visc2_r,0,0,0,1,2,2,2}, {&rh_state::diff2,0,0,0,RH_NCONS,2,2,2},
+    {&rh_state::rufrc,1,0,0,2,2,2,1}, {&rh_state::rvfrc,0,1,0,2,2,2,1},
+    {&rh_state::sustr,1,0,0,1,2,2,1}, {&rh_state::svstr,0,1,0,1,2,2,1}, {&rh_state::rdrag,0,0,0,1,2,2,1},
+    {&rh_state::bustr,1,0,0,1,2,2,1}, {&rh_state::bvstr,0,1,0,1,2,2,1},
+    {&rh_state::DU_avg1,1,0,0,1,2,2,1}, {&rh_state::DU_avg2,1,0,0,1,2,2,1},
+    {&rh_state::DV_avg1,0,1,0,1,2,2,1}, {&rh_state::DV_avg2,0,1,0,1,2,2,1},
+    {&rh_state::rubar,1,0,0,4,2,2,1}, {&rh_state::rvbar,0,1,0,4,2,2,1}, {&rh_state::rzeta,0,0,0,4,2,2,1},
+    {&rh_state::zeta,0,0,0,3,3,3,1},
+    {&rh_state::pm,0,0,0,1,3,4,1}, {&rh_state::pn,0,0,0,1,4,3,1}, {&rh_state::fcor,0,0,0,1,3,3,1},
+    {&rh_state::sstore,0,0,0,RH_NCONS,2,2,0},
+    {&rh_state::rhoS,0,0,0,1,2,2,1}, {&rh_state::rhoA,0,0,0,1,2,2,1}, {&rh_state::bvf,0,0,1,1,2,2,0},
+};
+
+static rh_array4 shape_of(const rh_ctx *c, int ix0, int ix1, int ix2, int nc, int ng0, int ng1, int kind)
+{
+    rh_array4 a; a.p = nullptr; a.ncomp = nc;
+    rh_box b = c->bx;
+    if (ix0) b.hi[0] += 1;
+    if (ix1) b.hi[1] += 1;
+    if (ix2) b.hi[2] += 1;
+    if (kind == 1) { b.lo[2] = 0; b.hi[2] = 0; }
+    if (kind == 2) { b.lo[2] = 0; b.hi[2] = 1; }
+    b = bx_grow(b, ng0, ng1, 0);
+    for (int d = 0; d < 3; d++) { a.lo[d] = b.lo[d]; a.hi[d] = b.hi[d]; }
+    return a;
+}
+static inline long align32(long ndbl) { return (ndbl + 31) / 32 * 32; }    // 256-B aligned carve
+
+extern "C" long rh_state_bytes(const rh_ctx *c)
+{
+    long n = 0;
+    for (const FieldSpec &f : g_fields) n += align32(a4_size(shape_of(c, f.ix0, f.ix1, f.ix2, f.nc, f.ng0, f.ng1, f.kind)));
+    return n * 8;
+}
+extern "C" int rh_state_bind(const rh_ctx *c, void *device_base, rh_state *out)
+{
+    if (((size_t)device_base) & 255) return rh_fail("rh_state_bind: base must be 256-byte aligned");
+    double *p = (double *)device_base;
+    for (const FieldSpec &f : g_fields) {
+        rh_array4 a = shape_of(c, f.ix0, f.ix1, f.ix2, f.nc, f.ng0, f.ng1, f.kind);
+        a.p = p; p += align32(a4_size(a));
+        out->*(f.m) = a;
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ create / destroy
+extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
+{
+    if (!prm || !out) return rh_fail("rh_create: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return rh_fail("rh_create: no HIP device visible -- this library has no CPU path");
+    rh_ctx *c = new rh_ctx();
+    c->prm = *prm; c->stream = (hipStream_t)stream;
+    for (int d = 0; d < 3; d++) { c->dom.lo[d] = prm->domain_lo[d]; c->dom.hi[d] = prm->domain_hi[d]; c->bx.lo[d] = prm->box_lo[d]; c->bx.hi[d] = prm->box_hi[d]; }
+    c->nz = c->dom.hi[2] - c->dom.lo[2] + 1; c->N = c->nz - 1;
+    auto bad = [&](const char *m) { delete c; return rh_fail("rh_create: %s", m); };
+    if (c->dom.lo[2] != 0) return bad("domain must start at k = 0");
+    if (c->nz < 3) return bad("at least 3 vertical levels are required (4th-order vertical fluxes index k = N-2)");
+    if (c->bx.lo[2] != c->dom.lo[2] || c->bx.hi[2] != c->dom.hi[2]) return bad("boxes must span the full vertical (main.cpp:21-23)");
+    if (!bx_contains(c->dom, c->bx)) return bad("box outside domain");
+    if (prm->ndtfast < 1) return bad("ndtfast < 1");
+    if (!(c->bx.lo[0] == c->dom.lo[0] && c->bx.hi[0] == c->dom.hi[0] && c->bx.lo[1] == c->dom.lo[1] && c->bx.hi[1] == c->dom.hi[1]))
+        return bad("i-j decomposed boxes need rh_comm_init (not available in this build): box must equal the domain");
+    for (int d = 0; d < 2; d++) if (prm->periodic[d] && (c->dom.hi[d] - c->dom.lo[d] + 1) < 4) return bad("periodic direction shorter than the ghost width");
+    c->nfast = set_weights(prm->ndtfast, c->w1, c->w2);
+    init_bcs(c);
+    c->poison = getenv("RH_POISON") && atoi(getenv("RH_POISON")) != 0;
+
+    // stretching curves (here N = nz, DepthStretchTransform.H:49)
+    const int nz = c->nz;
+    c->h_sc.assign(4 * (nz + 1), 0.0);
+    for (int k = 0; k <= nz; k++)
+        stretch_coeffs(k, nz, prm->theta_s, prm->theta_b, &c->h_sc[0 * (nz + 1) + k], &c->h_sc[1 * (nz + 1) + k], &c->h_sc[2 * (nz + 1) + k], &c->h_sc[3 * (nz + 1) + k]);
+    hipError_t e = hipMalloc((void **)&c->d_sc, sizeof(double) * c->h_sc.size());
+    if (e != hipSuccess) { delete c; return rh_fail("rh_create: hipMalloc failed: %s", hipGetErrorString(e)); }
+    e = hipMemcpy(c->d_sc, c->h_sc.data(), sizeof(double) * c->h_sc.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { delete c; return rh_fail("rh_create: hipMemcpy failed: %s", hipGetErrorString(e)); }
+
+    // work space: rho (setup_step.cpp:63), P (prsgrd.cpp:39), W (setup_step.cpp:210, advance_3d.cpp:230),
+    // CF/DC of the tridiagonal solve (advance_3d.cpp:49-51, vert_visc_3d.cpp), DUon/DVom (advance_2d.cpp:105-106)
+    c->rho  = shape_of(c, 0, 0, 0, 1, 2, 2, 0);
+    c->P    = shape_of(c, 0, 0, 0, 1, 1, 1, 0);
+    c->W    = shape_of(c, 0, 0, 1, 1, 3, 3, 0);
+    c->wCF  = shape_of(c, 1, 1, 1, 1, 0, 0, 0);
+    c->wDC  = shape_of(c, 1, 1, 1, 1, 0, 0, 0);
+    c->DUon = shape_of(c, 1, 0, 0, 1, 2, 2, 1);
+    c->DVom = shape_of(c, 0, 1, 0, 1, 2, 2, 1);
+    // 2-D intermediates of one advance_2d call (advance_2d.cpp:233-248): Drhs on grow 3, the rest on grow 2
+    c->Drhs = shape_of(c, 0, 0, 0, 1, 3, 3, 1);
+    c->Dnew = shape_of(c, 0, 0, 0, 1, 2, 2, 1); c->zwrk = c->Dnew; c->gzeta = c->Dnew; c->gzeta2 = c->Dnew; c->gzetaSA = c->Dnew;
+    rh_array4 *ws[] = {&c->rho, &c->P, &c->W, &c->wCF, &c->wDC, &c->DUon, &c->DVom, &c->Drhs, &c->Dnew, &c->zwrk, &c->gzeta, &c->gzeta2, &c->gzetaSA};
+    long n = 0; for (rh_array4 *a : ws) n += align32(a4_size(*a));
+    c->work_bytes = n * 8;
+    e = hipMalloc((void **)&c->d_work, c->work_bytes);
+    if (e != hipSuccess) { (void)hipFree(c->d_sc); delete c; return rh_fail("rh_create: hipMalloc(%ld bytes of work space) failed: %s", n * 8, hipGetErrorString(e)); }
+    double *p = c->d_work; for (rh_array4 *a : ws) { a->p = p; p += align32(a4_size(*a)); }
+    e = hipMemsetAsync(c->d_work, 0, c->work_bytes, c->stream);
+    if (e != hipSuccess) { (void)hipFree(c->d_sc); (void)hipFree(c->d_work); delete c; return rh_fail("rh_create: hipMemsetAsync failed: %s", hipGetErrorString(e)); }
+    *out = c;
+    return 0;
+}
+
+extern "C" int rh_destroy(rh_ctx *c)
+{
+    if (!c) return 0;
+    (void)hipStreamSynchronize(c->stream);
+    for (auto &v : c->tev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &e : c->evpool) (void)hipEventDestroy(e);
+    (void)hipFree(c->d_sc); (void)hipFree(c->d_work);
+    delete c;
+    return 0;
+}
+extern "C" int rh_nfast(const rh_ctx *c) { return c->nfast; }
+extern "C" int rh_weights(const rh_ctx *c, double *w1, double *w2)
+{
+    memcpy(w1, c->w1.data(), sizeof(double) * c->w1.size()); memcpy(w2, c->w2.data(), sizeof(double) * c->w2.size());
+    return 0;
+}
+extern "C" int rh_sync(rh_ctx *c) { RH_HIP(hipStreamSynchronize(c->stream)); return 0; }
+
+extern "C" void rh_swap_old_new(rh_state *s)
+{
+    std::swap(s->cons_old, s->cons_new); std::swap(s->xvel_old, s->xvel_new);
+    std::swap(s->yvel_old, s->yvel_new); std::swap(s->zvel_old, s->zvel_new);
+}

@@ -1,0 +1,308 @@
+// rh_halo.hip -- ghost-cell fills on device.
+//   halo_fill_boundary : amrex::FabArray::FillBoundary(periodicity) for a rank that owns the whole periodic extent
+//                        (what FillPatchSingleLevel reduces to at level 0, BoundaryConditions/REMORA_FillPatch.cpp:96-102)
+//   halo_physbc        : REMORAPhysBCFunct::operator() (BoundaryConditions/REMORA_PhysBCFunct.cpp:21-93) with
+//                        impose_{cons,xvel,yvel,zvel}_bcs (REMORA_BoundaryConditions_{cons,xvel,yvel,zvel}.cpp)
+//                        for int_dir / foextrap / ext_dir sides (periodic + SlipWall)
+#include "rh_common.h"
+
+// ---- periodic wrap: one thread per ghost point of the frame around the valid box -------------------------------
+// Ghost points are enumerated row-wise: first the full-width rows below/above the valid rows, then the two side
+// segments of every valid row.  Source search order (sx, then sy, -1..1) follows the single-box FillBoundary.
+__global__ void k_fill_periodic(A4 a, B3 v, int icomp, int ncomp, int perx, int pery, int lenx, int leny)
+{
+    const int NX = a.hi0 - a.lo0 + 1, NY = a.hi1 - a.lo1 + 1;
+    const int vx = v.hi0 - v.lo0 + 1, vy = v.hi1 - v.lo1 + 1;
+    const int nglo_x = v.lo0 - a.lo0, nglo_y = v.lo1 - a.lo1;
+    const long nrow_part = (long)(NY - vy) * NX;
+    const long per_k = nrow_part + (long)vy * (NX - vx);
+    const int nk = a.hi2 - a.lo2 + 1;
+    const long total = per_k * nk * ncomp;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        const int n = icomp + (int)(g / (per_k * nk));
+        long r = g % (per_k * nk);
+        const int k = a.lo2 + (int)(r / per_k);
+        r = r % per_k;
+        int i, j;
+        if (r < nrow_part) {
+            const int row = (int)(r / NX); i = a.lo0 + (int)(r % NX);
+            j = row < nglo_y ? a.lo1 + row : v.hi1 + 1 + (row - nglo_y);
+        } else {
+            r -= nrow_part;
+            const int w = NX - vx; const int row = (int)(r / w); const int cc = (int)(r % w);
+            j = v.lo1 + row;
+            i = cc < nglo_x ? a.lo0 + cc : v.hi0 + 1 + (cc - nglo_x);
+        }
+        bool done = false;
+        for (int sx = -1; sx <= 1 && !done; sx++) {
+            if (sx != 0 && !perx) continue;
+            for (int sy = -1; sy <= 1 && !done; sy++) {
+                if (sy != 0 && !pery) continue;
+                if (sx == 0 && sy == 0) continue;
+                const int ii = i + sx * lenx, jj = j + sy * leny;
+                if (ii >= v.lo0 && ii <= v.hi0 && jj >= v.lo1 && jj <= v.hi1) { a(i, j, k, n) = a(ii, jj, k, n); done = true; }
+            }
+        }
+    }
+}
+
+int halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp)
+{
+    const int perx = c->prm.periodic[0], pery = c->prm.periodic[1];
+    if (!perx && !pery) return 0;
+    if (icomp < 0 || icomp + ncomp > m.a.ncomp) return rh_fail("halo_fill_boundary: component range");
+    A4 a = mkA(m.a); B3 v = mkB(m.valid);
+    const long NX = a.hi0 - a.lo0 + 1, NY = a.hi1 - a.lo1 + 1, vx = v.hi0 - v.lo0 + 1, vy = v.hi1 - v.lo1 + 1;
+    if (vx <= 0 || vy <= 0 || !bx_contains(bx_of(m.a), m.valid)) return rh_fail("halo_fill_boundary: valid box not inside array");
+    const long total = ((NY - vy) * NX + vy * (NX - vx)) * (a.hi2 - a.lo2 + 1) * ncomp;
+    if (total <= 0) return 0;
+    long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
+    k_fill_periodic<<<(int)nb, 256, 0, c->stream>>>(a, v, icomp, ncomp, perx, pery,
+                                                     c->dom.hi[0] - c->dom.lo[0] + 1, c->dom.hi[1] - c->dom.lo[1] + 1);
+    RH_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- one pass of a physical-BC routine over a (small) region -------------------------------------------------
+enum { BCP_CONST = 0, BCP_COPY_I = 1, BCP_COPY_J = 2, BCP_CORNER = 3 };
+// dest(i,j,k) = val*msk | dest(si,j,k)*msk | dest(i,sj,k)*msk | 0.5*(dest(i,sj,k)+dest(si,j,k));  msk.p == null: no mask factor
+__global__ void k_bc_pass(A4 d, B3 r, int mode, int si, int sj, double val, A4 msk)
+{
+    const long nx = r.hi0 - r.lo0 + 1, ny = r.hi1 - r.lo1 + 1, nk = r.hi2 - r.lo2 + 1;
+    const long total = nx * ny * nk;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        const int i = r.lo0 + (int)(g % nx), j = r.lo1 + (int)((g / nx) % ny), k = r.lo2 + (int)(g / (nx * ny));
+        double x;
+        if (mode == BCP_CONST) x = val;
+        else if (mode == BCP_COPY_I) x = d(si, j, k);
+        else if (mode == BCP_COPY_J) x = d(i, sj, k);
+        else x = 0.5 * (d(i, sj, k) + d(si, j, k));
+        if (msk.p) x = x * msk(i, j, 0);
+        d(i, j, k) = x;
+    }
+}
+
+static int bc_pass(rh_ctx *c, const rh_array4 &dest, int comp, rh_box r, int mode, int si, int sj, double val, const rh_array4 *msk)
+{
+    r = bx_and(r, bx_of(dest));
+    if (!bx_ok(r)) return 0;
+    A4 d = mkA(dest, comp);
+    // every source index must lie inside the array
+    if ((mode == BCP_COPY_I || mode == BCP_CORNER) && (si < dest.lo[0] || si > dest.hi[0])) return rh_fail("bc_pass: source i outside array");
+    if ((mode == BCP_COPY_J || mode == BCP_CORNER) && (sj < dest.lo[1] || sj > dest.hi[1])) return rh_fail("bc_pass: source j outside array");
+    A4 m; memset(&m, 0, sizeof m);
+    if (msk) {
+        rh_box r2 = bx_slab(r, 2, 0);
+        if (!bx_contains(bx_of(*msk), r2)) return rh_fail("bc_pass: mask does not cover the region");
+        m = mkA(*msk);
+    }
+    const long total = bx_npts(r);
+    long nb = (total + 255) / 256; if (nb > 2048) nb = 2048;
+    k_bc_pass<<<(int)nb, 256, 0, c->stream>>>(d, mkB(r), mode, si, sj, val, m);
+    RH_LAUNCH_CHECK();
+    return 0;
+}
+
+// amrex::setBC: domain type where the box reaches the domain side, int_dir otherwise
+static BCRec3 setbc(const BCRec3 &d, const rh_box &bx, const rh_box &dom)
+{
+    BCRec3 r;
+    for (int k = 0; k < 3; k++) { r.lo[k] = bx.lo[k] <= dom.lo[k] ? d.lo[k] : RH_BC_INT_DIR; r.hi[k] = bx.hi[k] >= dom.hi[k] ? d.hi[k] : RH_BC_INT_DIR; }
+    return r;
+}
+static int supported(const BCRec3 &bc)
+{
+    for (int d = 0; d < 3; d++) for (int t : {bc.lo[d], bc.hi[d]})
+        if (t != RH_BC_INT_DIR && t != RH_BC_FOEXTRAP && t != RH_BC_EXT_DIR && t != -666) return rh_fail("physbc: BC type %d is not implemented on device", t);
+    return 0;
+}
+
+// REMORA_BoundaryConditions_cons.cpp:20-340
+static int impose_cons(rh_ctx *c, const MFV &m, const rh_array4 &mskr, int icomp, int ncomp, int bccomp, int nnf)
+{
+    const rh_box dom = c->dom, bx = bx_of(m.a), vb = m.valid;
+    const int perx = c->prm.periodic[0], pery = c->prm.periodic[1];
+    for (int n = 0; n < ncomp; n++) {
+        const BCRec3 bc = setbc(c->bcs[bccomp + n], bx, dom);                                    // :33-34
+        RH_TRY(supported(bc));
+        const double *ext = c->extdir[bccomp + n];
+        const int cc = icomp + n;
+        if (!perx) {                                                                             // :65-107
+            rh_box lo = bx; lo.hi[0] = dom.lo[0] - 1;
+            lo.lo[1] = std::max(vb.lo[1] - 1, dom.lo[1]); lo.hi[1] = std::min(vb.hi[1] + 1, dom.hi[1]);
+            rh_box hi = bx; hi.lo[0] = dom.hi[0] + 1; hi.lo[1] = lo.lo[1]; hi.hi[1] = lo.hi[1];
+            if (bc.lo[0] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, cc, lo, BCP_CONST, 0, 0, ext[0], &mskr));
+            if (bc.hi[0] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, cc, hi, BCP_CONST, 0, 0, ext[3], &mskr));
+        }
+        if (!pery) {                                                                             // :109-151
+            rh_box lo = bx; lo.hi[1] = dom.lo[1] - 1;
+            lo.lo[0] = std::max(vb.lo[0] - 1, dom.lo[0]); lo.hi[0] = std::min(vb.hi[0] + 1, dom.hi[0]);
+            rh_box hi = bx; hi.lo[1] = dom.hi[1] + 1; hi.lo[0] = lo.lo[0]; hi.hi[0] = lo.hi[0];
+            if (bc.lo[1] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, cc, lo, BCP_CONST, 0, 0, ext[1], &mskr));
+            if (bc.hi[1] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, cc, hi, BCP_CONST, 0, 0, ext[4], &mskr));
+        }
+        // z sides (:153-168, :254-286): the arrays on this path carry no ghost cells in z, nothing to fill
+        const int zl = std::max(dom.lo[2], bx.lo[2]), zh = std::min(dom.hi[2], bx.hi[2]);
+        // 2-D arrays sit on the k = 0 slab whatever the domain's k range
+        const int zlo = (bx.lo[2] == bx.hi[2]) ? bx.lo[2] : zl, zhi = (bx.lo[2] == bx.hi[2]) ? bx.hi[2] : zh;
+        rh_box xlo = bx; xlo.hi[0] = dom.lo[0] - 1 - nnf; xlo.lo[2] = zlo; xlo.hi[2] = zhi;      // :170-181
+        rh_box xhi = bx; xhi.lo[0] = dom.hi[0] + 1 + nnf; xhi.lo[2] = zlo; xhi.hi[2] = zhi;
+        rh_box ylo = bx; ylo.hi[1] = dom.lo[1] - 1 - nnf; ylo.lo[2] = zlo; ylo.hi[2] = zhi;
+        rh_box yhi = bx; yhi.lo[1] = dom.hi[1] + 1 + nnf; yhi.lo[2] = zlo; yhi.hi[2] = zhi;
+        if (!perx || bccomp == RH_BCV_FOEXTRAP) {                                                // :193-221
+            if (bc.lo[0] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, cc, xlo, BCP_COPY_I, dom.lo[0] - nnf, 0, 0.0, nullptr));
+            if (bc.hi[0] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, cc, xhi, BCP_COPY_I, dom.hi[0] + nnf, 0, 0.0, nullptr));
+        }
+        if (!pery || bccomp == RH_BCV_FOEXTRAP) {                                                // :223-252
+            if (bc.lo[1] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, cc, ylo, BCP_COPY_J, 0, dom.lo[1] - nnf, 0.0, nullptr));
+            if (bc.hi[1] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, cc, yhi, BCP_COPY_J, 0, dom.hi[1] + nnf, 0.0, nullptr));
+        }
+        if ((!perx && !pery) || bccomp == RH_BCV_FOEXTRAP) {                                     // :287-337
+            RH_TRY(bc_pass(c, m.a, cc, bx_and(xlo, ylo), BCP_CORNER, dom.lo[0], dom.lo[1], 0.0, nullptr));
+            RH_TRY(bc_pass(c, m.a, cc, bx_and(xlo, yhi), BCP_CORNER, dom.lo[0], dom.hi[1], 0.0, nullptr));
+            RH_TRY(bc_pass(c, m.a, cc, bx_and(xhi, ylo), BCP_CORNER, dom.hi[0], dom.lo[1], 0.0, nullptr));
+            RH_TRY(bc_pass(c, m.a, cc, bx_and(xhi, yhi), BCP_CORNER, dom.hi[0], dom.hi[1], 0.0, nullptr));
+        }
+    }
+    return 0;
+}
+
+// REMORA_BoundaryConditions_xvel.cpp:12-269
+static int impose_xvel(rh_ctx *c, const MFV &m, const rh_array4 &msku, int comp, int bccomp)
+{
+    const rh_box dom = c->dom, bx = bx_of(m.a);
+    const int perx = c->prm.periodic[0], pery = c->prm.periodic[1];
+    const BCRec3 bc = setbc(c->bcs[bccomp], bx, dom); const double *ext = c->extdir[bccomp];
+    RH_TRY(supported(bc));
+    const bool fx = (bccomp == RH_BCV_FOEXTRAP);
+    if (!perx || fx) {                                                                           // :56-134
+        rh_box xlo = bx; xlo.hi[0] = dom.lo[0] - 1; rh_box xhi = bx; xhi.lo[0] = dom.hi[0] + 2;
+        rh_box flo = bx; flo.lo[0] = flo.hi[0] = dom.lo[0]; rh_box fhi = bx; fhi.lo[0] = fhi.hi[0] = dom.hi[0] + 1;
+        xlo = bx_grow(xlo, 0, -1, 0); xhi = bx_grow(xhi, 0, -1, 0); flo = bx_grow(flo, 0, -1, 0); fhi = bx_grow(fhi, 0, -1, 0);
+        if (bc.lo[0] == RH_BC_EXT_DIR) { RH_TRY(bc_pass(c, m.a, comp, flo, BCP_CONST, 0, 0, ext[0], &msku)); RH_TRY(bc_pass(c, m.a, comp, xlo, BCP_CONST, 0, 0, ext[0], &msku)); }
+        else if (bc.lo[0] == RH_BC_FOEXTRAP) { RH_TRY(bc_pass(c, m.a, comp, flo, BCP_COPY_I, dom.lo[0] + 1, 0, 0.0, &msku)); RH_TRY(bc_pass(c, m.a, comp, xlo, BCP_COPY_I, dom.lo[0] + 1, 0, 0.0, &msku)); }
+        if (bc.hi[0] == RH_BC_EXT_DIR) { RH_TRY(bc_pass(c, m.a, comp, fhi, BCP_CONST, 0, 0, ext[3], &msku)); RH_TRY(bc_pass(c, m.a, comp, xhi, BCP_CONST, 0, 0, ext[3], &msku)); }
+        else if (bc.hi[0] == RH_BC_FOEXTRAP) { RH_TRY(bc_pass(c, m.a, comp, fhi, BCP_COPY_I, dom.hi[0], 0, 0.0, &msku)); RH_TRY(bc_pass(c, m.a, comp, xhi, BCP_COPY_I, dom.hi[0], 0, 0.0, &msku)); }
+    }
+    if (!pery || fx) {                                                                           // :136-191
+        rh_box ylo = bx; ylo.hi[1] = dom.lo[1] - 1; rh_box yhi = bx; yhi.lo[1] = dom.hi[1] + 1;
+        ylo = bx_grow(ylo, -1, 0, 0); yhi = bx_grow(yhi, -1, 0, 0);
+        if (bc.lo[1] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, ylo, BCP_CONST, 0, 0, ext[1], &msku));
+        else if (bc.lo[1] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, ylo, BCP_COPY_J, 0, dom.lo[1], 0.0, &msku));
+        if (bc.hi[1] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, yhi, BCP_CONST, 0, 0, ext[4], &msku));
+        else if (bc.hi[1] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, yhi, BCP_COPY_J, 0, dom.hi[1], 0.0, &msku));
+    }
+    // z sides (:193-223): no ghost cells in z on this path
+    if ((!perx || fx) && (!pery || fx)) {                                                        // :225-265
+        rh_box xlo = bx; xlo.hi[0] = dom.lo[0]; rh_box xhi = bx; xhi.lo[0] = dom.hi[0] + 1;
+        rh_box ylo = bx; ylo.hi[1] = dom.lo[1] - 1; rh_box yhi = bx; yhi.lo[1] = dom.hi[1] + 1;
+        RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, ylo), BCP_CORNER, dom.lo[0] + 1, dom.lo[1], 0.0, nullptr));
+        RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, yhi), BCP_CORNER, dom.lo[0] + 1, dom.hi[1], 0.0, nullptr));
+        RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, ylo), BCP_CORNER, dom.hi[0], dom.lo[1], 0.0, nullptr));
+        RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, yhi), BCP_CORNER, dom.hi[0], dom.hi[1], 0.0, nullptr));
+    }
+    return 0;
+}
+
+// REMORA_BoundaryConditions_yvel.cpp:12-268
+static int impose_yvel(rh_ctx *c, const MFV &m, const rh_array4 &mskv, int comp, int bccomp)
+{
+    const rh_box dom = c->dom, bx = bx_of(m.a);
+    const int perx = c->prm.periodic[0], pery = c->prm.periodic[1];
+    const BCRec3 bc = setbc(c->bcs[bccomp], bx, dom); const double *ext = c->extdir[bccomp];
+    RH_TRY(supported(bc));
+    const bool fx = (bccomp == RH_BCV_FOEXTRAP);
+    if (!perx || fx) {                                                                           // :55-110
+        rh_box xlo = bx; xlo.hi[0] = dom.lo[0] - 1; rh_box xhi = bx; xhi.lo[0] = dom.hi[0] + 1;
+        xlo = bx_grow(xlo, 0, -1, 0); xhi = bx_grow(xhi, 0, -1, 0);
+        if (bc.lo[0] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, xlo, BCP_CONST, 0, 0, ext[0], &mskv));
+        else if (bc.lo[0] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, xlo, BCP_COPY_I, dom.lo[0], 0, 0.0, &mskv));
+        if (bc.hi[0] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, xhi, BCP_CONST, 0, 0, ext[3], &mskv));
+        else if (bc.hi[0] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, xhi, BCP_COPY_I, dom.hi[0], 0, 0.0, &mskv));
+    }
+    if (!pery || fx) {                                                                           // :112-192
+        rh_box ylo = bx; ylo.hi[1] = dom.lo[1] - 1; rh_box yhi = bx; yhi.lo[1] = dom.hi[1] + 2;
+        rh_box flo = bx; flo.lo[1] = flo.hi[1] = dom.lo[1]; rh_box fhi = bx; fhi.lo[1] = fhi.hi[1] = dom.hi[1] + 1;
+        ylo = bx_grow(ylo, -1, 0, 0); yhi = bx_grow(yhi, -1, 0, 0); flo = bx_grow(flo, -1, 0, 0); fhi = bx_grow(fhi, -1, 0, 0);
+        if (bc.lo[1] == RH_BC_EXT_DIR) { RH_TRY(bc_pass(c, m.a, comp, flo, BCP_CONST, 0, 0, ext[1], &mskv)); RH_TRY(bc_pass(c, m.a, comp, ylo, BCP_CONST, 0, 0, ext[1], &mskv)); }
+        else if (bc.lo[1] == RH_BC_FOEXTRAP) { RH_TRY(bc_pass(c, m.a, comp, flo, BCP_COPY_J, 0, dom.lo[1] + 1, 0.0, &mskv)); RH_TRY(bc_pass(c, m.a, comp, ylo, BCP_COPY_J, 0, dom.lo[1] + 1, 0.0, &mskv)); }
+        if (bc.hi[1] == RH_BC_EXT_DIR) { RH_TRY(bc_pass(c, m.a, comp, fhi, BCP_CONST, 0, 0, ext[4], &mskv)); RH_TRY(bc_pass(c, m.a, comp, yhi, BCP_CONST, 0, 0, ext[4], &mskv)); }
+        else if (bc.hi[1] == RH_BC_FOEXTRAP) { RH_TRY(bc_pass(c, m.a, comp, fhi, BCP_COPY_J, 0, dom.hi[1], 0.0, &mskv)); RH_TRY(bc_pass(c, m.a, comp, yhi, BCP_COPY_J, 0, dom.hi[1], 0.0, &mskv)); }
+    }
+    if ((!perx || fx) && (!pery || fx)) {                                                        // :226-265
+        rh_box xlo = bx; xlo.hi[0] = dom.lo[0] - 1; rh_box xhi = bx; xhi.lo[0] = dom.hi[0] + 1;
+        rh_box ylo = bx; ylo.hi[1] = dom.lo[1]; rh_box yhi = bx; yhi.lo[1] = dom.hi[1] + 1;
+        RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, ylo), BCP_CORNER, dom.lo[0], dom.lo[1] + 1, 0.0, nullptr));
+        RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, yhi), BCP_CORNER, dom.lo[0], dom.hi[1], 0.0, nullptr));
+        RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, ylo), BCP_CORNER, dom.hi[0], dom.lo[1] + 1, 0.0, nullptr));
+        RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, yhi), BCP_CORNER, dom.hi[0], dom.hi[1], 0.0, nullptr));
+    }
+    return 0;
+}
+
+// REMORA_BoundaryConditions_zvel.cpp:13-124
+static int impose_zvel(rh_ctx *c, const MFV &m, int comp, int bccomp)
+{
+    const rh_box dom = c->dom, bx = bx_of(m.a);
+    const int perx = c->prm.periodic[0], pery = c->prm.periodic[1];
+    const BCRec3 bc = setbc(c->bcs[bccomp], bx, dom); const double *ext = c->extdir[bccomp];
+    RH_TRY(supported(bc));
+    const bool fx = (bccomp == RH_BCV_FOEXTRAP);
+    if (!perx || fx) {
+        rh_box xlo = bx; xlo.hi[0] = dom.lo[0] - 1; rh_box xhi = bx; xhi.lo[0] = dom.hi[0] + 1;
+        if (bc.lo[0] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, xlo, BCP_CONST, 0, 0, ext[0], nullptr));
+        else if (bc.lo[0] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, xlo, BCP_COPY_I, dom.lo[0], 0, 0.0, nullptr));
+        if (bc.hi[0] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, xhi, BCP_CONST, 0, 0, ext[3], nullptr));
+        else if (bc.hi[0] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, xhi, BCP_COPY_I, dom.hi[0], 0, 0.0, nullptr));
+    }
+    if (!pery || fx) {
+        rh_box ylo = bx; ylo.hi[1] = dom.lo[1] - 1; rh_box yhi = bx; yhi.lo[1] = dom.hi[1] + 1;
+        if (bc.lo[1] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, ylo, BCP_CONST, 0, 0, ext[1], nullptr));
+        else if (bc.lo[1] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, ylo, BCP_COPY_J, 0, dom.lo[1], 0.0, nullptr));
+        if (bc.hi[1] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, yhi, BCP_CONST, 0, 0, ext[4], nullptr));
+        else if (bc.hi[1] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, yhi, BCP_COPY_J, 0, dom.hi[1], 0.0, nullptr));
+    }
+    return 0;
+}
+
+// REMORA_PhysBCFunct.cpp:21-93
+int halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill)
+{
+    rh_box gdom = c->dom;
+    for (int d = 0; d < 3; d++) if (m.ix[d]) gdom.hi[d] += 1;
+    for (int d = 0; d < 2; d++) if (c->prm.periodic[d] && bccomp != RH_BCV_FOEXTRAP) { gdom.lo[d] -= m.ng[d]; gdom.hi[d] += m.ng[d]; }
+    rh_box bx = bx_of(m.a);
+    // only x-y extents decide (2-D arrays live on k = 0; no z ghost cells on this path)
+    gdom.lo[2] = bx.lo[2]; gdom.hi[2] = bx.hi[2];
+    if (bx_contains(gdom, bx)) return 0;
+    if (icomp < 0 || icomp + ncomp > m.a.ncomp) return rh_fail("halo_physbc: component range");
+    if (!m.ix[0] && !m.ix[1] && !m.ix[2]) return impose_cons(c, m, msk, icomp, ncomp, bccomp, n_not_fill);
+    if (ncomp != 1) return rh_fail("halo_physbc: velocity BCs take one component");
+    if (m.ix[0]) return impose_xvel(c, m, msk, icomp, bccomp);
+    if (m.ix[1]) return impose_yvel(c, m, msk, icomp, bccomp);
+    return impose_zvel(c, m, icomp, bccomp);
+}
+
+// REMORA::FillPatch at level 0 (BoundaryConditions/REMORA_FillPatch.cpp:96-125) == FillBoundary + physbc
+int halo_fillpatch(rh_ctx *c, const MFV &m, const rh_array4 &msk, int bccomp, int icomp, int ncomp)
+{
+    RH_TRY(halo_fill_boundary(c, m, icomp, ncomp));
+    return halo_physbc(c, m, msk, icomp, ncomp, bccomp, 0);
+}
+
+// ---- C ABI -----------------------------------------------------------------------------------------------------
+static MFV mfv_from_ng(const rh_ctx *c, const rh_array4 &a, const int ng[3])
+{
+    // index type follows from the array extent: valid = box shrunk by ng, compared with the rank's cell box
+    MFV m; m.a = a;
+    for (int d = 0; d < 3; d++) { m.valid.lo[d] = a.lo[d] + ng[d]; m.valid.hi[d] = a.hi[d] - ng[d]; m.ng[d] = ng[d]; }
+    for (int d = 0; d < 3; d++) m.ix[d] = (m.valid.hi[d] - m.valid.lo[d]) == (c->bx.hi[d] - c->bx.lo[d] + 1) ? 1 : 0;
+    if (a.lo[2] == a.hi[2]) m.ix[2] = 0;
+    return m;
+}
+extern "C" int rh_fill_boundary(rh_ctx *c, rh_array4 a, const int ng[3], int icomp, int ncomp)
+{ TScope t(c, "fill_boundary"); return halo_fill_boundary(c, mfv_from_ng(c, a, ng), icomp, ncomp); }
+extern "C" int rh_physbc(rh_ctx *c, rh_array4 a, const int ng[3], rh_array4 msk, int icomp, int ncomp, int bccomp)
+{ TScope t(c, "physbc"); return halo_physbc(c, mfv_from_ng(c, a, ng), msk, icomp, ncomp, bccomp, 0); }
+extern "C" int rh_fill_patch(rh_ctx *c, rh_array4 a, const int ng[3], rh_array4 msk, int bccomp, int icomp, int ncomp)
+{ TScope t(c, "fill_patch"); return halo_fillpatch(c, mfv_from_ng(c, a, ng), msk, bccomp, icomp, ncomp); }

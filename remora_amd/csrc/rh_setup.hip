@@ -1,0 +1,711 @@
+// rh_setup.hip -- device kernels of the predictor half of the baroclinic step (REMORA::setup_step and its leaves).
+//
+// Mapping: one thread per (i,j) column, i along the wavefront (64 consecutive i per wave => 512-B coalesced rows),
+// k marched in registers.  Horizontal neighbours are read straight from global memory: consecutive lanes read
+// consecutive addresses for every stencil offset, and the +-2 re-reads are served by L1/L2.  Every kernel fuses the
+// reference's chain of ParallelFor passes over scratch FABs (FX, FE, curv, grad, FC, DC, UFx, ...) into one sweep
+// with the same per-expression operation order (build with -ffp-contract=off), so results are bit-identical to the
+// pass-by-pass form.
+#include "rh_common.h"
+
+// ------------------------------------------------------------------------------------------------------------------
+// bottom stress, REMORA_setup_step.cpp:115-137
+__global__ void k_bstress(B3 ub, B3 vb, B3 un, A4 rdrag, A4 bustr, A4 bvstr, A4 uold, A4 vold)
+{
+    RH_IJ(un);
+    if (inb2(ub, i, j)) bustr(i, j, 0) = 0.5 * (rdrag(i - 1, j, 0) + rdrag(i, j, 0)) * (uold(i, j, 0));
+    if (inb2(vb, i, j)) bvstr(i, j, 0) = 0.5 * (rdrag(i, j - 1, 0) + rdrag(i, j, 0)) * (vold(i, j, 0));
+}
+int launch_bstress(rh_ctx *c, rh_state *s)
+{
+    const rh_box b2 = bx_slab(c->bx, 2, 0);
+    const rh_box ub = bx_grow(bx_nodal(b2, 0), 1, 1, 0), vb = bx_grow(bx_nodal(b2, 1), 1, 1, 0), un = bx_union(ub, vb);
+    RH_NEED(s->rdrag, bx_grow(b2, 1, 1, 0)); RH_NEED(s->bustr, ub); RH_NEED(s->bvstr, vb);
+    RH_NEED(s->xvel_old, ub); RH_NEED(s->yvel_old, vb);
+    k_bstress<<<grid2(un), rh_block(), 0, c->stream>>>(mkB(ub), mkB(vb), mkB(un), mkA(s->rdrag), mkA(s->bustr), mkA(s->bvstr),
+                                                       mkA(s->xvel_old), mkA(s->yvel_old));
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Huon / Hvom from the old velocities, REMORA_setup_step.cpp:187-197
+__global__ void k_massflux_old(B3 bu, B3 bv, B3 un, A4 Hz, A4 Huon, A4 Hvom, A4 uold, A4 vold, A4 pm, A4 pn)
+{
+    RH_IJ(un);
+    const int k = un.lo2 + (int)blockIdx.z;
+    if (inb2(bu, i, j)) { const double on_u = 2.0 / (pn(i - 1, j, 0) + pn(i, j, 0)); Huon(i, j, k) = 0.5 * (Hz(i, j, k) + Hz(i - 1, j, k)) * uold(i, j, k) * on_u; }
+    if (inb2(bv, i, j)) { const double om_v = 2.0 / (pm(i, j - 1, 0) + pm(i, j, 0)); Hvom(i, j, k) = 0.5 * (Hz(i, j, k) + Hz(i, j - 1, k)) * vold(i, j, k) * om_v; }
+}
+int launch_massflux_old(rh_ctx *c, rh_state *s)
+{
+    const rh_box bu = bx_of(s->Huon), bv = bx_of(s->Hvom), un = bx_union(bu, bv);
+    RH_NEED(s->Hz, bx_growlo_i(bu)); RH_NEED(s->Hz, bx_growlo_j(bv)); RH_NEED(s->xvel_old, bu); RH_NEED(s->yvel_old, bv);
+    RH_NEED(s->pn, bx_slab(bx_growlo_i(bu), 2, 0)); RH_NEED(s->pm, bx_slab(bx_growlo_j(bv), 2, 0));
+    k_massflux_old<<<grid3(un), rh_block(), 0, c->stream>>>(mkB(bu), mkB(bv), mkB(un), mkA(s->Hz), mkA(s->Huon), mkA(s->Hvom),
+                                                            mkA(s->xvel_old), mkA(s->yvel_old), mkA(s->pm), mkA(s->pn));
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REMORA::rho_eos, REMORA_rho_eos.cpp:22-99: linear EOS, vertical averages rhoA / rhoS, Brunt-Vaisala frequency.
+// One downward sweep per column (the reference makes three passes and re-reads rho twice).
+__global__ void k_rho_eos(B3 bx, A4 st, A4 rho, A4 rhoA, A4 rhoS, A4 bvf, A4 Hz, A4 z_w, A4 z_r, A4 h, A4 mskr, int N,
+                          double R0, double S0, double T0, double Tcoef, double Scoef, double rho0, double g)
+{
+    RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const double m = mskr(i, j, 0);
+    const double gorho0 = g / rho0;
+    double r_up = 0.0, z_up = 0.0, A = 0.0, S = 0.0;
+    for (int k = N; k >= 0; k--) {
+        const double r = (R0 - R0 * Tcoef * (st(i, j, k, 0) - T0) + R0 * Scoef * (st(i, j, k, 1) - S0) - 1000.0) * m;
+        rho(i, j, k) = r;
+        const double hz = Hz(i, j, k), zr = z_r(i, j, k);
+        if (k == N) { const double cff0 = r * hz; S = 0.5 * cff0 * hz; A = cff0; }
+        else {
+            const double cff1 = r * hz; S += hz * (A + 0.5 * cff1); A += cff1;
+            bvf(i, j, k + 1) = -gorho0 * (r_up - r) / (z_up - zr);
+        }
+        r_up = r; z_up = zr;
+    }
+    const double cff2 = 1.0 / rho0;
+    const double cff11 = 1.0 / (z_w(i, j, N + 1) + h(i, j, 0, 0));
+    A *= cff2 * cff11;
+    S *= 2.0 * cff11 * cff11 * cff2;
+    rhoA(i, j, 0) = A; rhoS(i, j, 0) = S;
+}
+extern "C" int rh_rho_eos(rh_ctx *c, rh_box bx, rh_array4 state, rh_array4 rho, rh_array4 rhoA, rh_array4 rhoS, rh_array4 bvf,
+                          rh_array4 Hz, rh_array4 z_w, rh_array4 z_r, rh_array4 h, rh_array4 mskr, int N)
+{
+    TScope t(c, "rho_eos");
+    const rh_box b2 = bx_slab(bx, 2, 0);
+    rh_box bw = bx; bw.lo[2] = 0; bw.hi[2] = N + 1;
+    bx.lo[2] = 0; bx.hi[2] = N;
+    if (state.ncomp < 2) return rh_fail("rh_rho_eos: state needs temp and salt");
+    RH_NEED(state, bx); RH_NEED(rho, bx); RH_NEED(Hz, bx); RH_NEED(z_r, bx); RH_NEED(z_w, bw); RH_NEED(bvf, bw);
+    RH_NEED(rhoA, b2); RH_NEED(rhoS, b2); RH_NEED(h, b2); RH_NEED(mskr, b2);
+    const rh_params &P = c->prm;
+    k_rho_eos<<<grid2(bx), rh_block(), 0, c->stream>>>(mkB(bx), mkA(state), mkA(rho), mkA(rhoA), mkA(rhoS), mkA(bvf), mkA(Hz),
+        mkA(z_w), mkA(z_r), mkA(h), mkA(mskr), N, P.R0, P.S0, P.T0, P.Tcoef, P.Scoef, P.rho0, P.g);
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// analytic vertical mixing = init_custom_vmix of Exec/<case>/prob.cpp (Upwelling/prob.cpp:163-185, Seamount/prob.cpp:167-190,
+// DoubleGyre/prob.cpp:116-138), which REMORA::set_analytical_vmix (REMORA.cpp:565-573) calls every step
+__global__ void k_vmix(B3 b, A4 Akv, A4 Akt, A4 z_w, int mode, double akv0, double akt0, double akt1, double akt2)
+{
+    RH_IJ(b); if (!inb2(b, i, j)) return;
+    const int k = b.lo2 + (int)blockIdx.z;
+    if (mode == RH_VMIX_UPWELLING) {
+        Akv(i, j, k) = 2.0e-03 + 8.0e-03 * exp(z_w(i, j, k) / 150.0);
+        Akt(i, j, k, 0) = 1.0e-6; Akt(i, j, k, 1) = 1.0e-6; Akt(i, j, k, 2) = 0.0;
+    } else {
+        Akv(i, j, k) = akv0; Akt(i, j, k, 0) = akt0; Akt(i, j, k, 1) = akt1; Akt(i, j, k, 2) = akt2;
+    }
+}
+int launch_vmix(rh_ctx *c, rh_state *s)
+{
+    rh_box b = bx_of(s->Akv);
+    if (s->Akt.ncomp < RH_NCONS) return rh_fail("vmix: Akt needs %d components", RH_NCONS);
+    RH_NEED(s->Akt, b);
+    if (c->prm.vmix_mode == RH_VMIX_UPWELLING) RH_NEED(s->z_w, b);
+    k_vmix<<<grid3(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(s->Akv), mkA(s->Akt), mkA(s->z_w), c->prm.vmix_mode,
+        c->prm.Akv_const, c->prm.Akt_const[0], c->prm.Akt_const[1], c->prm.Akt_const[2]);
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// set_zeta_to_Ztavg (REMORA_setup_step.cpp:208): zeta comps 0..2 := Zt_avg1
+__global__ void k_set_zeta(B3 b, A4 zeta, A4 Zt)
+{
+    RH_IJ(b); if (!inb2(b, i, j)) return;
+    const double z = Zt(i, j, 0);
+    zeta(i, j, 0, 0) = z; zeta(i, j, 0, 1) = z; zeta(i, j, 0, 2) = z;
+}
+int launch_set_zeta(rh_ctx *c, rh_state *s)
+{
+    const rh_box b = bx_grow(bx_slab(c->bx, 2, 0), 3, 3, 0);
+    RH_NEED(s->zeta, b); RH_NEED(s->Zt_avg1, b);
+    if (s->zeta.ncomp < 3) return rh_fail("set_zeta: zeta needs 3 components");
+    k_set_zeta<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(s->zeta), mkA(s->Zt_avg1));
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// omega: REMORA_prestep_t_advection.cpp:97-125 == REMORA_advance_3d.cpp:272-293.  Upward integration of the horizontal
+// flux divergence, then removal of the part proportional to (z_w + h).
+__global__ void k_omega(B3 b, A4 W, A4 Huon, A4 Hvom, A4 z_w, A4 h, int N)
+{
+    RH_IJ(b); if (!inb2(b, i, j)) return;
+    double w = 0.0;
+    W(i, j, 0) = 0.0;
+    for (int k = 1; k <= N + 1; k++) {
+        w = w - (Huon(i + 1, j, k - 1) - Huon(i, j, k - 1)) - (Hvom(i, j + 1, k - 1) - Hvom(i, j, k - 1));
+        W(i, j, k) = w;
+    }
+    const double hh = h(i, j, 0, 0);
+    const double wrk = w / (z_w(i, j, N + 1) + hh);
+    for (int k = 1; k <= N; k++) W(i, j, k) = W(i, j, k) - wrk * (z_w(i, j, k) + hh);
+    W(i, j, N + 1) = 0.0;
+}
+extern "C" int rh_omega(rh_ctx *c, rh_box gbx1, rh_array4 W, rh_array4 Huon, rh_array4 Hvom, rh_array4 z_w, rh_array4 h, int N)
+{
+    TScope t(c, "omega");
+    rh_box b = gbx1; b.lo[2] = 0; b.hi[2] = N; rh_box bw = b; bw.hi[2] = N + 1;
+    RH_NEED(W, bw); RH_NEED(z_w, bw); RH_NEED(Huon, bx_nodal(b, 0)); RH_NEED(Hvom, bx_nodal(b, 1)); RH_NEED(h, bx_slab(b, 2, 0));
+    k_omega<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(W), mkA(Huon), mkA(Hvom), mkA(z_w), mkA(h), N);
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// horizontal tracer flux through the x-face i (dir 0) or the y-face j (dir 1) of one level: third-order upstream or
+// fourth-order centred (REMORA_prestep_t_advection.cpp:161-266, REMORA_rhs_t_3d.cpp:87-276).
+//   t2,t1 = values at face-2, face-1 (below the face), t0,tp = face, face+1 (above); m1,m0,mp = face masks at face-1, face, face+1
+//   sgn = -1 (prestep, and rhs_t_3d with bathymetry) or +1 (rhs_t_3d, flat bathymetry: REMORA_rhs_t_3d.cpp:124-125,138-139)
+__device__ __forceinline__ double tflux_u3(double t2, double t1, double t0, double tp, double m1, double m0, double mp, double H, double sgn)
+{
+    const double g1 = (t1 - t2) * m1, g0 = (t0 - t1) * m0, gp = (tp - t0) * mp;
+    const double curv0 = -g0 + gp, curv1 = -g1 + g0;              // curv at cell face (=i) and at face-1
+    const double maxH = dmax_(H, 0.0), minH = dmin_(H, 0.0);
+    const double a = H * 0.5 * (t0 + t1), b = (1.0 / 6.0) * (curv0 * minH + curv1 * maxH);
+    return sgn < 0.0 ? a - b : a + b;
+}
+// mode 0: H*0.5*(t0+t1-cffb*(grad0-grad1))   (prestep and rhs_t_3d with bathymetry)
+// mode 1: H*0.5*(t0+t1)+cffb*(grad0+grad1)   (rhs_t_3d, flat bathymetry: REMORA_rhs_t_3d.cpp:138-139)
+__device__ __forceinline__ double tflux_c4(double t2, double t1, double t0, double tp, double m1, double m0, double mp, double H, int mode)
+{
+    const double g1 = (t1 - t2) * m1, g0 = (t0 - t1) * m0, gp = (tp - t0) * mp;
+    const double grad0 = 0.5 * (g0 + gp), grad1 = 0.5 * (g1 + g0);
+    const double cffb = 1.0 / 3.0;
+    return mode == 0 ? H * 0.5 * (t0 + t1 - cffb * (grad0 - grad1)) : H * 0.5 * (t0 + t1) + cffb * (grad0 + grad1);
+}
+// fourth-order vertical flux through k-face kk (REMORA_prestep_t_advection.cpp:304-332, REMORA_rhs_t_3d.cpp:301-326)
+__device__ __forceinline__ double tflux_w(const A4 &t, int i, int j, int kk, int N, double w)
+{
+    const double c1 = 0.5, c2 = 7.0 / 12.0, c3 = 1.0 / 12.0;
+    if (kk >= 2 && kk <= N - 1) return (c2 * (t(i, j, kk - 1) + t(i, j, kk)) - c3 * (t(i, j, kk - 2) + t(i, j, kk + 1))) * w;
+    if (kk == N + 1) return 0.0;
+    if (kk == N) return (c2 * t(i, j, N - 1) + c1 * t(i, j, N) - c3 * t(i, j, N - 2)) * w;
+    if (kk == 1) return (c2 * t(i, j, 1) + c1 * t(i, j, 0) - c3 * t(i, j, 2)) * w;
+    return 0.0;
+}
+
+// REMORA::prestep_t_advection after omega (REMORA_prestep_t_advection.cpp:127-361) fused with the tracer call of
+// REMORA::prestep_diffusion (REMORA_prestep_diffusion.cpp:19-165 with lambda = 1, zero surface/bottom tracer flux:
+// REMORA_prestep.cpp:101,166-170), one tracer.  The reference's 5-component cache copy (REMORA_prestep.cpp:63-70) is not needed:
+// tnew is read (as tempcache) and overwritten at the same point only.
+template <int SCHEME>   // 0 = upstream3, 1 = centered4, 2 = flat-bathymetry centred flux (REMORA_prestep_t_advection.cpp:147-157)
+__global__ void k_prestep_t(B3 bx, A4 told, A4 tnew, A4 ts, A4 Hz, A4 Huon, A4 Hvom, A4 W, A4 pm, A4 pn, A4 msku, A4 mskv,
+                            int N, double cff, double cff1, double cff2)
+{
+    RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const double pmn = cff * pm(i, j, 0) * pn(i, j, 0);
+    const double mu1 = msku(i - 1, j, 0), mu0 = msku(i, j, 0), mup = msku(i + 1, j, 0), mupp = msku(i + 2, j, 0);
+    const double mv1 = mskv(i, j - 1, 0), mv0 = mskv(i, j, 0), mvp = mskv(i, j + 1, 0), mvpp = mskv(i, j + 2, 0);
+    double FCk = 0.0, Wk = W(i, j, 0);
+    for (int k = 0; k <= N; k++) {
+        const double t0 = told(i, j, k);
+        const double tm2 = told(i - 2, j, k), tm1 = told(i - 1, j, k), tp1 = told(i + 1, j, k), tp2 = told(i + 2, j, k);
+        const double sm2 = told(i, j - 2, k), sm1 = told(i, j - 1, k), sp1 = told(i, j + 1, k), sp2 = told(i, j + 2, k);
+        const double Hu0 = Huon(i, j, k), Hu1 = Huon(i + 1, j, k), Hv0 = Hvom(i, j, k), Hv1 = Hvom(i, j + 1, k);
+        double FX0, FX1, FE0, FE1;
+        if (SCHEME == 2) {
+            FX0 = Hu0 * 0.5 * (tm1 + t0); FX1 = Hu1 * 0.5 * (t0 + tp1);
+            FE0 = Hv0 * 0.5 * (sm1 + t0); FE1 = Hv1 * 0.5 * (t0 + sp1);
+        } else if (SCHEME == 0) {
+            FX0 = tflux_u3(tm2, tm1, t0, tp1, mu1, mu0, mup, Hu0, -1.0); FX1 = tflux_u3(tm1, t0, tp1, tp2, mu0, mup, mupp, Hu1, -1.0);
+            FE0 = tflux_u3(sm2, sm1, t0, sp1, mv1, mv0, mvp, Hv0, -1.0); FE1 = tflux_u3(sm1, t0, sp1, sp2, mv0, mvp, mvpp, Hv1, -1.0);
+        } else {
+            FX0 = tflux_c4(tm2, tm1, t0, tp1, mu1, mu0, mup, Hu0, 0); FX1 = tflux_c4(tm1, t0, tp1, tp2, mu0, mup, mupp, Hu1, 0);
+            FE0 = tflux_c4(sm2, sm1, t0, sp1, mv1, mv0, mvp, Hv0, 0); FE1 = tflux_c4(sm1, t0, sp1, sp2, mv0, mvp, mvpp, Hv1, 0);
+        }
+        const double hz = Hz(i, j, k);
+        double store = hz * (cff1 * t0 + cff2 * tnew(i, j, k)) - pmn * (FX1 - FX0 + FE1 - FE0);
+        const double Wk1 = W(i, j, k + 1);
+        const double FCk1 = tflux_w(told, i, j, k + 1, N, Wk1);
+        const double DC = 1.0 / (hz - pmn * (Hu1 - Hu0 + Hv1 - Hv0 + (Wk1 - Wk)));
+        const double c4 = FCk1 - FCk;
+        ts(i, j, k) = DC * (store - pmn * c4);
+        tnew(i, j, k) = t0 * 0.5 * (hz + hz);
+        FCk = FCk1; Wk = Wk1;
+    }
+}
+extern "C" int rh_prestep_t(rh_ctx *c, rh_box tbx, rh_array4 told, rh_array4 tnew, rh_array4 tempstore, rh_array4 Hz,
+                            rh_array4 Huon, rh_array4 Hvom, rh_array4 W, rh_array4 pm, rh_array4 pn, rh_array4 msku, rh_array4 mskv,
+                            int iic, int ntfirst, int N, double dt)
+{
+    TScope t(c, "prestep_t");
+    tbx.lo[2] = 0; tbx.hi[2] = N;
+    const rh_box g2 = bx_grow(tbx, 2, 2, 0), b2 = bx_slab(tbx, 2, 0);
+    rh_box bw = tbx; bw.hi[2] = N + 1;
+    RH_NEED(told, g2); RH_NEED(tnew, tbx); RH_NEED(tempstore, tbx); RH_NEED(Hz, tbx); RH_NEED(W, bw);
+    RH_NEED(Huon, bx_nodal(tbx, 0)); RH_NEED(Hvom, bx_nodal(tbx, 1)); RH_NEED(pm, b2); RH_NEED(pn, b2);
+    { rh_box m = b2; m.lo[0] -= 1; m.hi[0] += 2; RH_NEED(msku, m); }
+    { rh_box m = b2; m.lo[1] -= 1; m.hi[1] += 2; RH_NEED(mskv, m); }
+    const double GammaT = 1.0 / 6.0;
+    double cff, cff1, cff2;
+    if (iic == ntfirst) { cff = 0.5 * dt; cff1 = 1.0; cff2 = 0.0; }
+    else { cff = (1.0 - GammaT) * dt; cff1 = 0.5 + GammaT; cff2 = 0.5 - GammaT; }
+    const int scheme = c->prm.flat_bathymetry ? 2 : (c->prm.tracer_c4 ? 1 : 0);
+#define RH_PT(S) k_prestep_t<S><<<grid2(tbx), rh_block(), 0, c->stream>>>(mkB(tbx), mkA(told), mkA(tnew), mkA(tempstore), mkA(Hz), \
+        mkA(Huon), mkA(Hvom), mkA(W), mkA(pm), mkA(pn), mkA(msku), mkA(mskv), N, cff, cff1, cff2)
+    if (scheme == 0) RH_PT(0); else if (scheme == 1) RH_PT(1); else RH_PT(2);
+#undef RH_PT
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REMORA::prestep_diffusion for u (ioff = 1) or v (joff = 1), REMORA_prestep_diffusion.cpp:19-165 with lambda = 1
+// (REMORA_prestep.cpp:101): vel*Hz + surface/bottom stress + Adams-Bashforth weighting of the stored right-hand sides,
+// including the in-place component swap of rvel (:128-131,154-161).
+__global__ void k_prestep_uv(B3 bx, int ioff, int joff, A4 vel, A4 vel_old, A4 rvel, A4 Hz, A4 sstr, A4 bstr, A4 pm, A4 pn,
+                             int step, int nrhs, int N, double dt)
+{
+    RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const int ii = i - ioff, jj = j - joff;
+    const double DC = 0.25 * dt * (pm(i, j, 0) + pm(ii, jj, 0)) * (pn(i, j, 0) + pn(ii, jj, 0));
+    const double sb = dt * bstr(i, j, 0), ss = dt * sstr(i, j, 0);
+    const int indx = nrhs ? 0 : 1;
+    for (int k = 0; k <= N; k++) {
+        const double a = vel_old(i, j, k) * 0.5 * (Hz(i, j, k) + Hz(ii, jj, k));
+        // FC(k) = dt*(1-lambda)*... = 0 for k < N, FC(N) = dt*sstr
+        const double b = (k == 0) ? 0.0 - sb : (k == N ? ss - 0.0 : 0.0 - 0.0);
+        if (step == 0) vel(i, j, k) = a + b;
+        else {
+            const double r_indx = rvel(i, j, k, indx), r_nrhs = rvel(i, j, k, nrhs);
+            // swap
+            rvel(i, j, k, indx) = r_nrhs;
+            if (step == 1) {
+                rvel(i, j, k, nrhs) = r_indx;
+                const double cff3 = 0.5 * DC;
+                vel(i, j, k) = a - cff3 * r_nrhs + b;
+            } else {
+                const double cff1 = 5.0 / 12.0, cff2 = 16.0 / 12.0;
+                vel(i, j, k) = a + DC * (cff1 * r_indx - cff2 * r_nrhs) + b;
+                rvel(i, j, k, nrhs) = 0.0;
+            }
+        }
+    }
+}
+extern "C" int rh_prestep_uv(rh_ctx *c, rh_box vel_bx, int ioff, int joff, rh_array4 vel, rh_array4 vel_old, rh_array4 rvel,
+                             rh_array4 Hz, rh_array4 sstr, rh_array4 bstr, rh_array4 pm, rh_array4 pn,
+                             int iic, int ntfirst, int nrhs, int N, double dt)
+{
+    TScope t(c, "prestep_uv");
+    if ((ioff | joff) != 1 || (ioff & joff)) return rh_fail("rh_prestep_uv: (ioff,joff) must be (1,0) or (0,1)");
+    vel_bx.lo[2] = 0; vel_bx.hi[2] = N;
+    rh_box bs = vel_bx; bs.lo[0] -= ioff; bs.lo[1] -= joff;
+    const rh_box b2 = bx_slab(vel_bx, 2, 0), bs2 = bx_slab(bs, 2, 0);
+    if (rvel.ncomp < 2) return rh_fail("rh_prestep_uv: rvel needs 2 components");
+    RH_NEED(vel, vel_bx); RH_NEED(vel_old, vel_bx); RH_NEED(rvel, vel_bx); RH_NEED(Hz, bs);
+    RH_NEED(sstr, b2); RH_NEED(bstr, b2); RH_NEED(pm, bs2); RH_NEED(pn, bs2);
+    const int step = (iic == ntfirst) ? 0 : (iic == ntfirst + 1 ? 1 : 2);
+    k_prestep_uv<<<grid2(vel_bx), rh_block(), 0, c->stream>>>(mkB(vel_bx), ioff, joff, mkA(vel), mkA(vel_old), mkA(rvel), mkA(Hz),
+        mkA(sstr), mkA(bstr), mkA(pm), mkA(pn), step, nrhs, N, dt);
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REMORA::prsgrd, REMORA_prsgrd.cpp:6-197 (density-Jacobian pressure gradient with harmonic-mean slopes).
+// Kernel 1: hydrostatic pressure P, one downward sweep per column (:54-99); the vertical slopes dR, dZ are a
+// 3-level window in registers instead of two scratch FABs.
+__device__ __forceinline__ double hmean_eps(double a, double b)   // :65-67 / :91-96 pattern: 2ab/(a+b) if 2ab > eps else 0
+{
+    const double eps = 1.0E-10;
+    const double cff = 2.0 * a * b;
+    return cff > eps ? cff / (a + b) : 0.0;
+}
+__global__ void k_prsgrd_P(B3 bx, A4 P, A4 rho, A4 z_r, A4 z_w, int N, double GRho, double GRho0, double HalfGRho)
+{
+    RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
+    // raw differences: d(k) = f(k+1)-f(k) for k<N, d(N) = f(N)-f(N-1)
+    double rN = rho(i, j, N), rN1 = rho(i, j, N - 1), zN = z_r(i, j, N), zN1 = z_r(i, j, N - 1);
+    {
+        const double cff1 = 1.0 / (zN - zN1);
+        const double zw = z_w(i, j, N + 1);
+        const double cff2 = 0.5 * (rN - rN1) * (zw - zN) * cff1;
+        P(i, j, N) = GRho0 * zw + GRho * (rN + cff2) * (zw - zN);
+    }
+    // harmonic slopes at level N: raw d(N) and raw d(N-1) are both f(N)-f(N-1)
+    double dRraw_k1 = rN - rN1, dZraw_k1 = zN - zN1;               // raw d(k+1) with k+1 = N
+    double dRraw_k = rN - rN1, dZraw_k = zN - zN1;                 // raw d(k) with k = N-1
+    double dRh_k1 = hmean_eps(dRraw_k1, dRraw_k);
+    double dZh_k1 = 2.0 * dZraw_k1 * dZraw_k / (dZraw_k1 + dZraw_k);
+    double r_k1 = rN, z_k1 = zN, r_k = rN1, z_k = zN1, Pk1 = P(i, j, N);
+    for (int k = N - 1; k >= 0; k--) {
+        // raw d(k-1) (or d(0) itself at k = 0)
+        double r_km = 0.0, z_km = 0.0, dRraw_km, dZraw_km;
+        if (k > 0) { r_km = rho(i, j, k - 1); z_km = z_r(i, j, k - 1); dRraw_km = r_k - r_km; dZraw_km = z_k - z_km; }
+        else { dRraw_km = dRraw_k; dZraw_km = dZraw_k; }
+        const double dRh_k = hmean_eps(dRraw_k, dRraw_km);
+        const double dZh_k = 2.0 * dZraw_k * dZraw_km / (dZraw_k + dZraw_km);
+        const double rho_diff = r_k1 - r_k - OneTwelfth * (dRh_k1 + dRh_k);
+        const double z_diff = z_k1 - z_k - OneTwelfth * (dZh_k1 + dZh_k);
+        const double rz_avg = (r_k1 + r_k) * (z_k1 - z_k);
+        const double Pk = Pk1 + HalfGRho * (rz_avg - OneFifth * ((dRh_k1 - dRh_k) * z_diff - (dZh_k1 - dZh_k) * rho_diff));
+        P(i, j, k) = Pk;
+        Pk1 = Pk; dRh_k1 = dRh_k; dZh_k1 = dZh_k; r_k1 = r_k; z_k1 = z_k; r_k = r_km; z_k = z_km;
+        dRraw_k = dRraw_km; dZraw_k = dZraw_km;
+    }
+}
+// Kernel 2: ru, rv (:103-196), pointwise in k.  The horizontal slopes dRx, dZx are rebuilt from a 4-point window.
+__device__ __forceinline__ double hmean_inv(double a, double b)    // :91-96: cff = 2ab; cff > eps ? cff*(1/(a+b)) : 0
+{
+    const double eps = 1.0E-10;
+    const double cff = 2.0 * a * b;
+    if (cff > eps) { const double cff1 = 1.0 / (b + a); return cff * cff1; }
+    return 0.0;
+}
+__global__ void k_prsgrd_uv(B3 ub, B3 vb, B3 un, A4 ru, A4 rv, A4 pn, A4 pm, A4 rho, A4 P, A4 Hz, A4 z_r, A4 msku, A4 mskv,
+                            int nrhs, double HalfGRho)
+{
+    RH_IJ(un);
+    const int k = un.lo2 + (int)blockIdx.z;
+    const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
+    if (inb2(ub, i, j)) {
+        const double r2 = rho(i - 2, j, k), r1 = rho(i - 1, j, k), r0 = rho(i, j, k), rp = rho(i + 1, j, k);
+        const double z2 = z_r(i - 2, j, k), z1 = z_r(i - 1, j, k), z0 = z_r(i, j, k), zp = z_r(i + 1, j, k);
+        const double m1 = msku(i - 1, j, 0), m0 = msku(i, j, 0), mp = msku(i + 1, j, 0);
+        const double FC1 = (r1 - r2) * m1, FC0 = (r0 - r1) * m0, FCp = (rp - r0) * mp;
+        const double ax1 = (z1 - z2) * m1, ax0 = (z0 - z1) * m0, axp = (zp - z0) * mp;
+        const double dZx0 = hmean_inv(ax0, axp), dZx1 = hmean_inv(ax1, ax0);
+        const double dRx0 = hmean_inv(FCp, FC0), dRx1 = hmean_inv(FC0, FC1);
+        const double rho_diff = r0 - r1 - OneTwelfth * (dRx0 + dRx1);
+        const double z_r_diff = z0 - z1 - OneTwelfth * (dZx0 + dZx1);
+        const double Hz_avg = 0.5 * (Hz(i, j, k) + Hz(i - 1, j, k));
+        const double on_u = 2.0 / (pn(i - 1, j, 0) + pn(i, j, 0));
+        ru(i, j, k, nrhs) = on_u * Hz_avg * (P(i - 1, j, k) - P(i, j, k) - HalfGRho *
+            ((r0 + r1) * (z0 - z1) - OneFifth * ((dRx0 - dRx1) * z_r_diff - (dZx0 - dZx1) * rho_diff)));
+    }
+    if (inb2(vb, i, j)) {
+        const double r2 = rho(i, j - 2, k), r1 = rho(i, j - 1, k), r0 = rho(i, j, k), rp = rho(i, j + 1, k);
+        const double z2 = z_r(i, j - 2, k), z1 = z_r(i, j - 1, k), z0 = z_r(i, j, k), zp = z_r(i, j + 1, k);
+        const double m1 = mskv(i, j - 1, 0), m0 = mskv(i, j, 0), mp = mskv(i, j + 1, 0);
+        const double FC1 = (r1 - r2) * m1, FC0 = (r0 - r1) * m0, FCp = (rp - r0) * mp;
+        const double ax1 = (z1 - z2) * m1, ax0 = (z0 - z1) * m0, axp = (zp - z0) * mp;
+        const double dZx0 = hmean_inv(ax0, axp), dZx1 = hmean_inv(ax1, ax0);
+        const double dRx0 = hmean_inv(FCp, FC0), dRx1 = hmean_inv(FC0, FC1);
+        const double rho_diff = r0 - r1 - OneTwelfth * (dRx0 + dRx1);
+        const double z_r_diff = z0 - z1 - OneTwelfth * (dZx0 + dZx1);
+        const double Hz_avg = 0.5 * (Hz(i, j, k) + Hz(i, j - 1, k));
+        const double om_v = 2.0 / (pm(i, j - 1, 0) + pm(i, j, 0));
+        rv(i, j, k, nrhs) = om_v * Hz_avg * (P(i, j - 1, k) - P(i, j, k) - HalfGRho *
+            ((r0 + r1) * (z0 - z1) - OneFifth * ((dRx0 - dRx1) * z_r_diff - (dZx0 - dZx1) * rho_diff)));
+    }
+}
+extern "C" int rh_prsgrd(rh_ctx *c, rh_box phi_bx, rh_box utbx, rh_box vtbx, rh_array4 ru, rh_array4 rv, rh_array4 pn, rh_array4 pm,
+                         rh_array4 rho, rh_array4 P, rh_array4 Hz, rh_array4 z_r, rh_array4 z_w, rh_array4 msku, rh_array4 mskv,
+                         int nrhs, int N)
+{
+    TScope t(c, "prsgrd");
+    phi_bx.lo[2] = 0; phi_bx.hi[2] = N; utbx.lo[2] = 0; utbx.hi[2] = N; vtbx.lo[2] = 0; vtbx.hi[2] = N;
+    rh_box bw = phi_bx; bw.lo[2] = bw.hi[2] = N + 1;
+    RH_NEED(P, phi_bx); RH_NEED(rho, phi_bx); RH_NEED(z_r, phi_bx); RH_NEED(z_w, bw);
+    const rh_params &Pm = c->prm;
+    const double GRho = Pm.g / Pm.rho0, GRho0 = 1000.0 * GRho, HalfGRho = 0.5 * GRho;
+    k_prsgrd_P<<<grid2(phi_bx), rh_block(), 0, c->stream>>>(mkB(phi_bx), mkA(P), mkA(rho), mkA(z_r), mkA(z_w), N, GRho, GRho0, HalfGRho);
+    RH_LAUNCH_CHECK();
+    rh_box us = utbx; us.lo[0] -= 2; us.hi[0] += 1; rh_box vs = vtbx; vs.lo[1] -= 2; vs.hi[1] += 1;
+    RH_NEED(rho, us); RH_NEED(rho, vs); RH_NEED(z_r, us); RH_NEED(z_r, vs);
+    { rh_box q = utbx; q.lo[0] -= 1; RH_NEED(P, q); RH_NEED(Hz, q); RH_NEED(pn, bx_slab(q, 2, 0)); q.hi[0] += 1; RH_NEED(msku, bx_slab(q, 2, 0)); }
+    { rh_box q = vtbx; q.lo[1] -= 1; RH_NEED(P, q); RH_NEED(Hz, q); RH_NEED(pm, bx_slab(q, 2, 0)); q.hi[1] += 1; RH_NEED(mskv, bx_slab(q, 2, 0)); }
+    RH_NEED(ru, utbx); RH_NEED(rv, vtbx);
+    if (nrhs < 0 || nrhs >= ru.ncomp || nrhs >= rv.ncomp) return rh_fail("rh_prsgrd: nrhs out of range");
+    const rh_box un = bx_union(utbx, vtbx);
+    k_prsgrd_uv<<<grid3(un), rh_block(), 0, c->stream>>>(mkB(utbx), mkB(vtbx), mkB(un), mkA(ru), mkA(rv), mkA(pn), mkA(pm), mkA(rho),
+        mkA(P), mkA(Hz), mkA(z_r), mkA(msku), mkA(mskv), nrhs, HalfGRho);
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REMORA::t3dmix, REMORA_t3dmix.cpp:6-58: harmonic tracer diffusion along s-surfaces, one component per launch.
+// d2 carries the reference's coefficient lookup: diff2(i,j,n) is a 3-index Array4 access, i.e. level k = n of
+// component 0 (:34,43), so the caller passes the (k, component) pair that the reference actually reads.
+__global__ void k_t3dmix(B3 bx, A4 st, A4 rhs, A4 d2, int d2k, A4 Hz, A4 pm, A4 pn, A4 msku, A4 mskv, double dt)
+{
+    RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const int k = bx.lo2 + (int)blockIdx.z;
+    const double r0 = rhs(i, j, k), hz0 = Hz(i, j, k);
+    double FX0, FX1, FE0, FE1;
+    {
+        const double pmon_u = (pm(i - 1, j, 0) + pm(i, j, 0)) / (pn(i - 1, j, 0) + pn(i, j, 0));
+        const double cff = 0.25 * (d2(i, j, d2k) + d2(i - 1, j, d2k)) * pmon_u;
+        FX0 = cff * (hz0 + Hz(i - 1, j, k)) * (r0 - rhs(i - 1, j, k)); FX0 *= msku(i, j, 0);
+    }
+    {
+        const double pmon_u = (pm(i, j, 0) + pm(i + 1, j, 0)) / (pn(i, j, 0) + pn(i + 1, j, 0));
+        const double cff = 0.25 * (d2(i + 1, j, d2k) + d2(i, j, d2k)) * pmon_u;
+        FX1 = cff * (Hz(i + 1, j, k) + hz0) * (rhs(i + 1, j, k) - r0); FX1 *= msku(i + 1, j, 0);
+    }
+    {
+        const double pnom_v = (pn(i, j - 1, 0) + pn(i, j, 0)) / (pm(i, j - 1, 0) + pm(i, j, 0));
+        const double cff = 0.25 * (d2(i, j, d2k) + d2(i, j - 1, d2k)) * pnom_v;
+        FE0 = cff * (hz0 + Hz(i, j - 1, k)) * (r0 - rhs(i, j - 1, k)); FE0 *= mskv(i, j, 0);
+    }
+    {
+        const double pnom_v = (pn(i, j, 0) + pn(i, j + 1, 0)) / (pm(i, j, 0) + pm(i, j + 1, 0));
+        const double cff = 0.25 * (d2(i, j + 1, d2k) + d2(i, j, d2k)) * pnom_v;
+        FE1 = cff * (Hz(i, j + 1, k) + hz0) * (rhs(i, j + 1, k) - r0); FE1 *= mskv(i, j + 1, 0);
+    }
+    const double cff = dt * pm(i, j, 0) * pn(i, j, 0);
+    st(i, j, k) += cff * ((FX1 - FX0) + (FE1 - FE0));
+}
+extern "C" int rh_t3dmix(rh_ctx *c, rh_box bx, rh_array4 state, rh_array4 state_rhs, rh_array4 diff2, rh_array4 Hz, rh_array4 pm,
+                         rh_array4 pn, rh_array4 msku, rh_array4 mskv, double dt, int ncomp)
+{
+    TScope t(c, "t3dmix");
+    const rh_box g1 = bx_grow(bx, 1, 1, 0), g12 = bx_slab(g1, 2, 0);
+    if (ncomp > state.ncomp || ncomp > state_rhs.ncomp) return rh_fail("rh_t3dmix: ncomp exceeds the arrays");
+    RH_NEED(state, bx); RH_NEED(state_rhs, g1); RH_NEED(Hz, g1); RH_NEED(pm, g12); RH_NEED(pn, g12);
+    { rh_box m = bx_slab(bx, 2, 0); m.hi[0] += 1; RH_NEED(msku, m); }
+    { rh_box m = bx_slab(bx, 2, 0); m.hi[1] += 1; RH_NEED(mskv, m); }
+    for (int n = 0; n < ncomp; n++) {
+        rh_box dk = g12; dk.lo[2] = dk.hi[2] = n; RH_NEED(diff2, dk);
+        k_t3dmix<<<grid3(bx), rh_block(), 0, c->stream>>>(mkB(bx), mkA(state, n), mkA(state_rhs, n), mkA(diff2), n, mkA(Hz), mkA(pm), mkA(pn),
+            mkA(msku), mkA(mskv), dt);
+        RH_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REMORA::coriolis + REMORA::rhs_uv_3d, REMORA_coriolis.cpp:10-40 and REMORA_rhs_uv_3d.cpp:31-385.
+// One upward sweep per column: Coriolis term, horizontal advection (third-order upstream, Gadv = -1/4, or centred second
+// order), fourth-order vertical advection with W averaged to the velocity point, and the vertical integrals rufrc / rvfrc
+// with surface and bottom stress.  UFx/UFe/VFx/VFe/FC never touch memory.
+struct UVGeom { int dlox, dhix, dloy, dhiy, perx, pery; };
+
+template <int C2>
+__device__ __forceinline__ double f_UFx(const A4 &u, const A4 &Hu, int i, int j, int k, const UVGeom &g)
+{
+    if (C2) return 0.25 * (u(i, j, k) + u(i + 1, j, k)) * (Hu(i, j, k) + Hu(i + 1, j, k));
+    const double Gadv = -0.25;
+    const double um = u(i - 1, j, k), u0 = u(i, j, k), up = u(i + 1, j, k), upp = u(i + 2, j, k);
+    const double hm = Hu(i - 1, j, k), h0 = Hu(i, j, k), hp = Hu(i + 1, j, k), hpp = Hu(i + 2, j, k);
+    const double cff1 = u0 + up;
+    double uxx_i = um - 2.0 * u0 + up, uxx_ip1 = u0 - 2.0 * up + upp;
+    double Huxx_i = hm - 2.0 * h0 + hp, Huxx_ip1 = h0 - 2.0 * hp + hpp;
+    if (i == g.dlox && !g.perx) { uxx_i = uxx_ip1; Huxx_i = Huxx_ip1; }
+    else if (i == g.dhix && !g.perx) { uxx_ip1 = uxx_i; Huxx_ip1 = Huxx_i; }
+    const double cff = (cff1 > 0.0) ? uxx_i : uxx_ip1;
+    const double Huon_avg = (h0 + hp);
+    return 0.25 * (cff1 + Gadv * cff) * (Huon_avg + 0.5 * Gadv * (Huxx_i + Huxx_ip1));
+}
+template <int C2>
+__device__ __forceinline__ double f_UFe(const A4 &u, const A4 &Hv, int i, int j, int k, const UVGeom &g)
+{
+    if (C2) return 0.25 * (u(i, j - 1, k) + u(i, j, k)) * (Hv(i - 1, j, k) + Hv(i, j, k));
+    const double Gadv = -0.25;
+    const double umm = u(i, j - 2, k), um = u(i, j - 1, k), u0 = u(i, j, k), up = u(i, j + 1, k);
+    const double hmm = Hv(i - 2, j, k), hm = Hv(i - 1, j, k), h0 = Hv(i, j, k), hp = Hv(i + 1, j, k);
+    const double cff1 = u0 + um;
+    const double cff2 = h0 + hm;
+    double uee_jm1 = umm - 2.0 * um + u0, uee_j = um - 2.0 * u0 + up;
+    if (j == g.dloy && !g.pery) uee_jm1 = uee_j;
+    else if (j == g.dhiy + 1 && !g.pery) uee_j = uee_jm1;
+    const double cff = (cff2 > 0.0) ? uee_jm1 : uee_j;
+    const double Hvxx_i = hm - 2.0 * h0 + hp, Hvxx_im1 = hmm - 2.0 * hm + h0;
+    return 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * (Hvxx_i + Hvxx_im1));
+}
+template <int C2>
+__device__ __forceinline__ double f_VFx(const A4 &v, const A4 &Hu, int i, int j, int k, const UVGeom &g)
+{
+    if (C2) return 0.25 * (v(i - 1, j, k) + v(i, j, k)) * (Hu(i, j - 1, k) + Hu(i, j, k));
+    const double Gadv = -0.25;
+    const double vmm = v(i - 2, j, k), vm = v(i - 1, j, k), v0 = v(i, j, k), vp = v(i + 1, j, k);
+    const double hmm = Hu(i, j - 2, k), hm = Hu(i, j - 1, k), h0 = Hu(i, j, k), hp = Hu(i, j + 1, k);
+    const double cff1 = v0 + vm;
+    const double cff2 = h0 + hm;
+    double vxx_im1 = vmm - 2.0 * vm + v0, vxx_i = vm - 2.0 * v0 + vp;
+    if (i == g.dlox && !g.perx) vxx_im1 = vxx_i;
+    else if (i == g.dhix + 1 && !g.perx) vxx_i = vxx_im1;
+    const double cff = (cff2 > 0.0) ? vxx_im1 : vxx_i;
+    const double Huee_j = hm - 2.0 * h0 + hp, Huee_jm1 = hmm - 2.0 * hm + h0;
+    return 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * (Huee_j + Huee_jm1));
+}
+template <int C2>
+__device__ __forceinline__ double f_VFe(const A4 &v, const A4 &Hv, int i, int j, int k, const UVGeom &g)
+{
+    if (C2) return 0.25 * (v(i, j, k) + v(i, j + 1, k)) * (Hv(i, j, k) + Hv(i, j + 1, k));
+    const double Gadv = -0.25;
+    const double vm = v(i, j - 1, k), v0 = v(i, j, k), vp = v(i, j + 1, k), vpp = v(i, j + 2, k);
+    const double hm = Hv(i, j - 1, k), h0 = Hv(i, j, k), hp = Hv(i, j + 1, k), hpp = Hv(i, j + 2, k);
+    const double cff1 = v0 + vp;
+    double vee_j = vm - 2.0 * v0 + vp, vee_jp1 = v0 - 2.0 * vp + vpp;
+    double Hvee_j = hm - 2.0 * h0 + hp, Hvee_jp1 = h0 - 2.0 * hp + hpp;
+    if (j == g.dloy && !g.pery) { vee_j = vee_jp1; Hvee_j = Hvee_jp1; }
+    else if (j == g.dhiy && !g.pery) { vee_jp1 = vee_j; Hvee_jp1 = Hvee_j; }
+    const double cff = (cff1 > 0.0) ? vee_j : vee_jp1;
+    return 0.25 * (cff1 + Gadv * cff) * (h0 + hp + 0.5 * Gadv * (Hvee_j + Hvee_jp1));
+}
+// vertical momentum flux through k-face kk at a u point (di=1,dj=0) or v point (di=0,dj=1), REMORA_rhs_uv_3d.cpp:168-198,319-345
+template <int C2>
+__device__ __forceinline__ double f_FCw(const A4 &q, const A4 &W, int i, int j, int kk, int N, int di, int dj)
+{
+    if (kk <= 0 || kk >= N + 1) return 0.0;
+    if (C2) return 0.25 * (q(i, j, kk - 1) + q(i, j, kk)) * (W(i, j, kk) + W(i - di, j - dj, kk));
+    const double cff1 = 9.0 / 16.0, cff2 = 1.0 / 16.0;
+    const double wpart = (cff1 * (W(i, j, kk) + W(i - di, j - dj, kk)) - cff2 * (W(i + di, j + dj, kk) + W(i - 2 * di, j - 2 * dj, kk)));
+    if (kk > 1 && kk <= N - 1)
+        return (cff1 * (q(i, j, kk - 1) + q(i, j, kk)) - cff2 * (q(i, j, kk - 2) + q(i, j, kk + 1))) * wpart;
+    if (kk == N)     // also the k = 1 face when N == 1 is excluded by rh_create (nz >= 3)
+        return (cff1 * (q(i, j, N - 1) + q(i, j, N)) - cff2 * (q(i, j, N - 2) + q(i, j, N))) * wpart;
+    return (cff1 * (q(i, j, 0) + q(i, j, 1)) - cff2 * (q(i, j, 0) + q(i, j, 2))) * wpart;          // kk == 1
+}
+
+template <int C2>
+__global__ void k_rhs_uv_3d(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4 rvfrc, A4 sustr, A4 svstr,
+                            A4 bustr, A4 bvstr, A4 Huon, A4 Hvom, A4 pm, A4 pn, A4 W, A4 Hz, A4 fcor, int use_cor, int nrhs, int N, UVGeom g)
+{
+    RH_IJ(un);
+    if (inb2(xb, i, j)) {
+        double fm0 = 0.0, fm1 = 0.0;
+        if (use_cor) { fm0 = fcor(i, j, 0) * (1.0 / (pm(i, j, 0) * pn(i, j, 0))); fm1 = fcor(i - 1, j, 0) * (1.0 / (pm(i - 1, j, 0) * pn(i - 1, j, 0))); }
+        double frc = rufrc(i, j, 0);
+        const double om_u = 2.0 / (pm(i - 1, j, 0) + pm(i, j, 0)), on_u = 2.0 / (pn(i - 1, j, 0) + pn(i, j, 0));
+        const double cffs = om_u * on_u;
+        const double s_top = sustr(i, j, 0) * cffs, s_bot = -bustr(i, j, 0) * cffs;
+        double FCk = 0.0;
+        for (int k = 0; k <= N; k++) {
+            double r = ru(i, j, k, nrhs);
+            if (use_cor) {
+                const double UFx_i = 0.5 * Hz(i, j, k) * fm0 * (vold(i, j, k) + vold(i, j + 1, k));
+                const double UFx_im1 = 0.5 * Hz(i - 1, j, k) * fm1 * (vold(i - 1, j, k) + vold(i - 1, j + 1, k));
+                r += 0.5 * (UFx_i + UFx_im1);
+            }
+            r -= ((f_UFx<C2>(uold, Huon, i, j, k, g) - f_UFx<C2>(uold, Huon, i - 1, j, k, g)) +
+                  (f_UFe<C2>(uold, Hvom, i, j + 1, k, g) - f_UFe<C2>(uold, Hvom, i, j, k, g)));
+            const double FCk1 = f_FCw<C2>(uold, W, i, j, k + 1, N, 1, 0);
+            const double cff = FCk1 - FCk;
+            r -= cff;
+            ru(i, j, k, nrhs) = r;
+            frc += r;
+            const double c1 = (k == N) ? s_top : 0.0, c2 = (k == 0) ? s_bot : 0.0;
+            frc += c1 + c2;
+            FCk = FCk1;
+        }
+        rufrc(i, j, 0) = frc;
+    }
+    if (inb2(yb, i, j)) {
+        double fm0 = 0.0, fm1 = 0.0;
+        if (use_cor) { fm0 = fcor(i, j, 0) * (1.0 / (pm(i, j, 0) * pn(i, j, 0))); fm1 = fcor(i, j - 1, 0) * (1.0 / (pm(i, j - 1, 0) * pn(i, j - 1, 0))); }
+        double frc = rvfrc(i, j, 0);
+        const double om_v = 2.0 / (pm(i, j - 1, 0) + pm(i, j, 0)), on_v = 2.0 / (pn(i, j - 1, 0) + pn(i, j, 0));
+        const double cffs = om_v * on_v;
+        const double s_top = svstr(i, j, 0) * cffs, s_bot = -bvstr(i, j, 0) * cffs;
+        double FCk = 0.0;
+        for (int k = 0; k <= N; k++) {
+            double r = rv(i, j, k, nrhs);
+            if (use_cor) {
+                const double VFe_j = 0.5 * Hz(i, j, k) * fm0 * (uold(i, j, k) + uold(i + 1, j, k));
+                const double VFe_jm1 = 0.5 * Hz(i, j - 1, k) * fm1 * (uold(i, j - 1, k) + uold(i + 1, j - 1, k));
+                r -= 0.5 * (VFe_j + VFe_jm1);
+            }
+            r -= ((f_VFx<C2>(vold, Huon, i + 1, j, k, g) - f_VFx<C2>(vold, Huon, i, j, k, g)) +
+                  (f_VFe<C2>(vold, Hvom, i, j, k, g) - f_VFe<C2>(vold, Hvom, i, j - 1, k, g)));
+            const double FCk1 = f_FCw<C2>(vold, W, i, j, k + 1, N, 0, 1);
+            const double cff = FCk1 - FCk;
+            r -= cff;
+            rv(i, j, k, nrhs) = r;
+            frc += r;
+            const double c1 = (k == N) ? s_top : 0.0, c2 = (k == 0) ? s_bot : 0.0;
+            frc += c1 + c2;
+            FCk = FCk1;
+        }
+        rvfrc(i, j, 0) = frc;
+    }
+}
+extern "C" int rh_rhs_uv_3d(rh_ctx *c, rh_box xbx, rh_box ybx, rh_array4 uold, rh_array4 vold, rh_array4 ru, rh_array4 rv,
+                            rh_array4 rufrc, rh_array4 rvfrc, rh_array4 sustr, rh_array4 svstr, rh_array4 bustr, rh_array4 bvstr,
+                            rh_array4 Huon, rh_array4 Hvom, rh_array4 pm, rh_array4 pn, rh_array4 W, rh_array4 Hz, rh_array4 fcor,
+                            int use_coriolis, int nrhs, int N)
+{
+    TScope t(c, "rhs_uv_3d");
+    xbx.lo[2] = 0; xbx.hi[2] = N; ybx.lo[2] = 0; ybx.hi[2] = N;
+    if (nrhs != 0) return rh_fail("rh_rhs_uv_3d: nrhs must be 0 (uold/vold are single-component, REMORA_setup_step.cpp:43)");
+    // stencil extents: u: i-2..i+2 / j-2..j+2 ; Huon i-2..i+2 ; Hvom i-2..i+1, j..j+1 ; W i-2..i+1
+    { rh_box q = bx_grow(xbx, 2, 2, 0); RH_NEED(uold, q); }
+    { rh_box q = bx_grow(ybx, 2, 2, 0); RH_NEED(vold, q); }
+    { rh_box q = xbx; q.lo[0] -= 2; q.hi[0] += 2; RH_NEED(Huon, q); q = xbx; q.lo[0] -= 2; q.hi[0] += 1; q.hi[1] += 1; RH_NEED(Hvom, q); }
+    { rh_box q = ybx; q.lo[1] -= 2; q.hi[1] += 2; RH_NEED(Hvom, q); q = ybx; q.lo[1] -= 2; q.hi[1] += 1; q.hi[0] += 1; RH_NEED(Huon, q); }
+    { rh_box q = xbx; q.lo[0] -= 2; q.hi[0] += 1; q.hi[2] = N + 1; RH_NEED(W, q); q = ybx; q.lo[1] -= 2; q.hi[1] += 1; q.hi[2] = N + 1; RH_NEED(W, q); }
+    { rh_box q = xbx; q.lo[0] -= 1; q.hi[1] += 1; RH_NEED(vold, q); RH_NEED(Hz, bx_growlo_i(xbx)); q = ybx; q.lo[1] -= 1; q.hi[0] += 1; RH_NEED(uold, q); RH_NEED(Hz, bx_growlo_j(ybx)); }
+    const rh_box x2 = bx_slab(xbx, 2, 0), y2 = bx_slab(ybx, 2, 0);
+    RH_NEED(ru, xbx); RH_NEED(rv, ybx); RH_NEED(rufrc, x2); RH_NEED(rvfrc, y2); RH_NEED(sustr, x2); RH_NEED(svstr, y2); RH_NEED(bustr, x2); RH_NEED(bvstr, y2);
+    RH_NEED(pm, bx_growlo_i(x2)); RH_NEED(pn, bx_growlo_i(x2)); RH_NEED(pm, bx_growlo_j(y2)); RH_NEED(pn, bx_growlo_j(y2));
+    if (use_coriolis) { RH_NEED(fcor, bx_growlo_i(x2)); RH_NEED(fcor, bx_growlo_j(y2)); }
+    UVGeom g = {c->dom.lo[0], c->dom.hi[0], c->dom.lo[1], c->dom.hi[1], c->prm.periodic[0], c->prm.periodic[1]};
+    const rh_box un = bx_union(xbx, ybx);
+#define RH_UV(C2) k_rhs_uv_3d<C2><<<grid2(un), rh_block(), 0, c->stream>>>(mkB(xbx), mkB(ybx), mkB(un), mkA(uold), mkA(vold), mkA(ru), mkA(rv), \
+        mkA(rufrc), mkA(rvfrc), mkA(sustr), mkA(svstr), mkA(bustr), mkA(bvstr), mkA(Huon), mkA(Hvom), mkA(pm), mkA(pn), mkA(W), mkA(Hz), mkA(fcor), \
+        use_coriolis, nrhs, N, g)
+    if (c->prm.uv_c2) RH_UV(1); else RH_UV(0);
+#undef RH_UV
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// REMORA::uv3dmix, REMORA_uv3dmix.cpp:6-149: harmonic viscosity along s-surfaces.  Stress at rho points (UFx, VFe) and at
+// psi points (UFe, VFx); shared with the 2-D call of the barotropic step (REMORA_advance_2d.cpp:536-538) in rh_step2d.hip.
+#include "rh_uvmix.h"
+
+__global__ void k_uv3dmix(B3 xb, B3 yb, B3 un, A4 u, A4 v, A4 uold, A4 vold, A4 rufrc, A4 rvfrc, A4 visc2_p, A4 visc2_r, A4 Hz,
+                          A4 pm, A4 pn, A4 mskp, int N, double dt)
+{
+    RH_IJ(un);
+    if (inb2(xb, i, j)) {
+        const MixR r0 = mix_r_metrics(pm, pn, visc2_r, i, j), r1 = mix_r_metrics(pm, pn, visc2_r, i - 1, j);
+        const MixP p0 = mix_p_metrics(pm, pn, visc2_p, mskp, i, j), p1 = mix_p_metrics(pm, pn, visc2_p, mskp, i, j + 1);
+        const double spm = pm(i - 1, j, 0) + pm(i, j, 0), spn = pn(i - 1, j, 0) + pn(i, j, 0);
+        const double cff = dt * 0.25 * spm * spn;
+        double frc = rufrc(i, j, 0);
+        for (int k = 0; k <= N; k++) {
+            const double UFx0 = r0.on_r * r0.on_r * r0.visc * mix_r_cff(r0, Hz, uold, vold, i, j, k);
+            const double UFx1 = r1.on_r * r1.on_r * r1.visc * mix_r_cff(r1, Hz, uold, vold, i - 1, j, k);
+            const double UFe0 = p0.om_p * p0.om_p * p0.visc * mix_p_cff(p0, Hz, uold, vold, i, j, k);
+            const double UFe1 = p1.om_p * p1.om_p * p1.visc * mix_p_cff(p1, Hz, uold, vold, i, j + 1, k);
+            const double cff1 = 0.5 * spn * (UFx0 - UFx1);
+            const double cff2 = 0.5 * spm * (UFe1 - UFe0);
+            const double cff3 = cff * (cff1 + cff2);
+            u(i, j, k) = u(i, j, k) + cff3;
+            frc += cff1 + cff2;
+        }
+        rufrc(i, j, 0) = frc;
+    }
+    if (inb2(yb, i, j)) {
+        const MixR r0 = mix_r_metrics(pm, pn, visc2_r, i, j), r1 = mix_r_metrics(pm, pn, visc2_r, i, j - 1);
+        const MixP p0 = mix_p_metrics(pm, pn, visc2_p, mskp, i, j), p1 = mix_p_metrics(pm, pn, visc2_p, mskp, i + 1, j);
+        const double spm = pm(i, j, 0) + pm(i, j - 1, 0), spn = pn(i, j, 0) + pn(i, j - 1, 0);
+        const double cff = dt * 0.25 * spm * spn;
+        const double spn2 = pn(i, j - 1, 0) + pn(i, j, 0), spm2 = pm(i, j - 1, 0) + pm(i, j, 0);
+        double frc = rvfrc(i, j, 0);
+        for (int k = 0; k <= N; k++) {
+            const double VFe0 = r0.om_r * r0.om_r * r0.visc * mix_r_cff(r0, Hz, uold, vold, i, j, k);
+            const double VFe1 = r1.om_r * r1.om_r * r1.visc * mix_r_cff(r1, Hz, uold, vold, i, j - 1, k);
+            const double VFx0 = p0.on_p * p0.on_p * p0.visc * mix_p_cff(p0, Hz, uold, vold, i, j, k);
+            const double VFx1 = p1.on_p * p1.on_p * p1.visc * mix_p_cff(p1, Hz, uold, vold, i + 1, j, k);
+            const double cff1 = 0.5 * spn2 * (VFx1 - VFx0);
+            const double cff2 = 0.5 * spm2 * (VFe0 - VFe1);
+            const double cff3 = cff * (cff1 - cff2);
+            v(i, j, k) = v(i, j, k) + cff3;
+            frc += cff1 - cff2;
+        }
+        rvfrc(i, j, 0) = frc;
+    }
+}
+extern "C" int rh_uv3dmix(rh_ctx *c, rh_box xbx, rh_box ybx, rh_array4 u, rh_array4 v, rh_array4 uold, rh_array4 vold,
+                          rh_array4 rufrc, rh_array4 rvfrc, rh_array4 visc2_p, rh_array4 visc2_r, rh_array4 Hz, rh_array4 pm,
+                          rh_array4 pn, rh_array4 mskp, int nrhs, int nnew, double dt)
+{
+    TScope t(c, "uv3dmix");
+    const int N = xbx.hi[2] - ybx.lo[2];                                       // REMORA_uv3dmix.cpp:36
+    if (nrhs != 0 || nnew != 0) return rh_fail("rh_uv3dmix: nrhs and nnew must be 0 for the 3-D call");
+    if (xbx.lo[2] != 0 || ybx.lo[2] != 0) return rh_fail("rh_uv3dmix: boxes must start at k = 0");
+    const rh_box un = bx_union(xbx, ybx);
+    { rh_box q = bx_grow(un, 1, 1, 0); RH_NEED(uold, q); RH_NEED(vold, q); RH_NEED(Hz, q);
+      rh_box q2 = bx_slab(q, 2, 0); RH_NEED(pm, q2); RH_NEED(pn, q2); RH_NEED(visc2_r, q2); RH_NEED(visc2_p, q2); RH_NEED(mskp, q2); }
+    RH_NEED(u, xbx); RH_NEED(v, ybx); RH_NEED(rufrc, bx_slab(xbx, 2, 0)); RH_NEED(rvfrc, bx_slab(ybx, 2, 0));
+    k_uv3dmix<<<grid2(un), rh_block(), 0, c->stream>>>(mkB(xbx), mkB(ybx), mkB(un), mkA(u), mkA(v), mkA(uold), mkA(vold), mkA(rufrc), mkA(rvfrc),
+        mkA(visc2_p), mkA(visc2_r), mkA(Hz), mkA(pm), mkA(pn), mkA(mskp), N, dt);
+    RH_LAUNCH_CHECK(); return 0;
+}

@@ -1,0 +1,423 @@
+// rh_step2d.hip -- the barotropic fast step: REMORA::advance_2d (= ROMS step2d), REMORA_advance_2d.cpp:41-757, with
+// REMORA::rhs_uv_2d (REMORA_rhs_uv_2d.cpp:20-238) and the 2-D calls of coriolis / uv3dmix folded in.
+//
+// The reference issues ~35 ParallelFor passes over 13 scratch FABs per call; here a call is three kernels
+//   k2d_flux   : Drhs, DUon, DVom                                             (:149-166)
+//   k2d_zeta   : time-average accumulation + free-surface step + rzeta          (:293-464)
+//   k2d_uvbar  : pressure gradient, advection, Coriolis, viscosity, 3D->2D forcing coupling, ubar/vbar step   (:479-730)
+// separated only where a ghost exchange (:170-171) or a neighbour dependency forces it.  One thread per (i,j).
+#include "rh_common.h"
+#include "rh_uvmix.h"
+
+__global__ void k2d_flux(B3 b3, B3 xg, B3 yg, A4 zeta, A4 h, A4 ubar, A4 vbar, A4 pm, A4 pn, A4 Drhs, A4 DUon, A4 DVom)
+{
+    RH_IJ(b3); if (!inb2(b3, i, j)) return;
+    const double d0 = zeta(i, j, 0) + h(i, j, 0);
+    Drhs(i, j, 0) = d0;
+    if (inb2(xg, i, j)) {
+        const double on_u = 2.0 / (pn(i, j, 0) + pn(i - 1, j, 0));
+        const double cff1 = 0.5 * on_u * (d0 + (zeta(i - 1, j, 0) + h(i - 1, j, 0)));
+        DUon(i, j, 0) = ubar(i, j, 0) * cff1;
+    }
+    if (inb2(yg, i, j)) {
+        const double om_v = 2.0 / (pm(i, j, 0) + pm(i, j - 1, 0));
+        const double cff1 = 0.5 * om_v * (d0 + (zeta(i, j - 1, 0) + h(i, j - 1, 0)));
+        DVom(i, j, 0) = vbar(i, j, 0) * cff1;
+    }
+}
+
+struct ZetaPar {
+    int avg_mode;            // 0: predictor & first, 1: predictor & not first, 2: corrector
+    double wt_a, wt_b;       // avg_mode 0: wt_b = cff2 ; 1: wt_a = cff1_wt1, wt_b = cff2_wt1 ; 2: wt_b = cff2_wt2
+    int do_step;             // my_iif < nfast
+    int zmode;               // 0: my_iif == 0 (forward Euler), 1: predictor (leap-frog), 2: corrector (Adams-Moulton)
+    int predictor;
+    double dtfast;
+};
+
+__global__ void k2d_zeta(B3 g3, B3 xg, B3 yg, B3 t1, ZetaPar zp, A4 zeta_rhs, A4 zeta_stp, A4 zeta_new_o, A4 rzeta_stp, A4 rzeta_pts,
+                         A4 rzeta_rhs, A4 h, A4 pm, A4 pn, A4 mskr, A4 rhoS, A4 rhoA, A4 DUon, A4 DVom, A4 Zt_avg1,
+                         A4 DU_avg1, A4 DU_avg2, A4 DV_avg1, A4 DV_avg2, A4 Dnew, A4 zwrk_o, A4 gzeta_o, A4 gzeta2_o, A4 gzetaSA_o)
+{
+    RH_IJ(g3); if (!inb2(g3, i, j)) return;
+    // ---- time averages, :293-356
+    if (zp.avg_mode == 0) {
+        Zt_avg1(i, j, 0) = 0.0;
+        if (inb2(xg, i, j)) { DU_avg1(i, j, 0) = 0.0; DU_avg2(i, j, 0) = zp.wt_b * DUon(i, j, 0); }
+        if (inb2(yg, i, j)) { DV_avg1(i, j, 0) = 0.0; DV_avg2(i, j, 0) = zp.wt_b * DVom(i, j, 0); }
+    } else if (zp.avg_mode == 1) {
+        Zt_avg1(i, j, 0) += zp.wt_a * zeta_rhs(i, j, 0);
+        if (inb2(xg, i, j)) { const double d = DUon(i, j, 0); DU_avg1(i, j, 0) += zp.wt_a * d; DU_avg2(i, j, 0) += zp.wt_b * d; }
+        if (inb2(yg, i, j)) { const double d = DVom(i, j, 0); DV_avg1(i, j, 0) += zp.wt_a * d; DV_avg2(i, j, 0) += zp.wt_b * d; }
+    } else {
+        if (inb2(xg, i, j)) DU_avg2(i, j, 0) = DU_avg2(i, j, 0) + zp.wt_b * DUon(i, j, 0);
+        if (inb2(yg, i, j)) DV_avg2(i, j, 0) = DV_avg2(i, j, 0) + zp.wt_b * DVom(i, j, 0);
+    }
+    if (!zp.do_step || !inb2(t1, i, j)) return;
+    // ---- free surface, :379-464
+    const double fac = 1000.0 / 1025.0;                                        // :379
+    const double div = (DUon(i, j, 0) - DUon(i + 1, j, 0)) + (DVom(i, j, 0) - DVom(i, j + 1, 0));
+    const double zs = zeta_stp(i, j, 0), hh = h(i, j, 0), rS = rhoS(i, j, 0), rA = rhoA(i, j, 0);
+    double zn, zw;
+    if (zp.zmode == 0) {
+        const double cff1 = zp.dtfast;
+        zn = (zs + pm(i, j, 0) * pn(i, j, 0) * cff1 * div) * mskr(i, j, 0);
+        zw = 0.5 * (zs + zn);
+    } else if (zp.zmode == 1) {
+        const double cff1 = 2.0 * zp.dtfast, cff4 = 4.0 / 25.0, cff5 = 1.0 - 2.0 * cff4;
+        zn = (zs + pm(i, j, 0) * pn(i, j, 0) * cff1 * div) * mskr(i, j, 0);
+        zw = cff5 * zeta_rhs(i, j, 0) + cff4 * (zs + zn);
+    } else {
+        const double cff1 = zp.dtfast * 5.0 / 12.0, cff2 = zp.dtfast * 8.0 / 12.0, cff3 = zp.dtfast * 1.0 / 12.0, cff4 = 2.0 / 5.0, cff5 = 1.0 - cff4;
+        const double cff = cff1 * div;
+        zn = zs + pm(i, j, 0) * pn(i, j, 0) * (cff + cff2 * rzeta_stp(i, j, 0) - cff3 * rzeta_pts(i, j, 0));
+        zn *= mskr(i, j, 0);
+        zw = cff5 * zn + cff4 * zeta_rhs(i, j, 0);
+    }
+    Dnew(i, j, 0) = zn + hh;
+    zwrk_o(i, j, 0) = zw;
+    const double gz = (fac + rS) * zw;
+    gzeta_o(i, j, 0) = gz;
+    gzeta2_o(i, j, 0) = gz * zw;
+    gzetaSA_o(i, j, 0) = zw * (rS - rA);
+    zeta_new_o(i, j, 0) = zn;                                                  // :450-454
+    if (zp.predictor) rzeta_rhs(i, j, 0) = div;                                // :459-464
+}
+
+struct UVPar {
+    int dlox, dhix, dloy, dhiy, perx, pery, uv_c2, use_cor;
+    int couple;              // 0: rhs += rufrc ; 1: iic == ntfirst ; 2: iic == ntfirst+1 ; 3: later (first && predictor), :543-624
+    int am3;                 // 0: my_iif == 0 || predictor (:643-684) ; 1: corrector (:686-713)
+    int predictor;
+    double g, c1, c2, c3;    // step coefficients
+};
+
+// 2-D momentum advection fluxes, REMORA_rhs_uv_2d.cpp:80-129,171-216 (u, v = ubar/vbar(krhs))
+__device__ __forceinline__ double s2_UFx(const A4 &u, const A4 &DU, int i, int j, const UVPar &g)
+{
+    if (g.uv_c2) return 0.25 * (DU(i, j, 0) + DU(i + 1, j, 0)) * (u(i, j, 0) + u(i + 1, j, 0));
+    const double um = u(i - 1, j, 0), u0 = u(i, j, 0), up = u(i + 1, j, 0), upp = u(i + 2, j, 0);
+    const double hm = DU(i - 1, j, 0), h0 = DU(i, j, 0), hp = DU(i + 1, j, 0), hpp = DU(i + 2, j, 0);
+    double uxx_i = um - 2.0 * u0 + up, uxx_ip1 = u0 - 2.0 * up + upp;
+    double Huxx_i = hm - 2.0 * h0 + hp, Huxx_ip1 = h0 - 2.0 * hp + hpp;
+    if (i == g.dlox && !g.perx) { uxx_i = uxx_ip1; Huxx_i = Huxx_ip1; }
+    else if (i == g.dhix && !g.perx) { uxx_ip1 = uxx_i; Huxx_ip1 = Huxx_i; }
+    const double cff = 1.0 / 6.0;
+    const double ubar_avg = u0 + up;
+    return 0.25 * (ubar_avg - cff * (uxx_i + uxx_ip1)) * (h0 + hp - cff * (Huxx_i + Huxx_ip1));
+}
+__device__ __forceinline__ double s2_UFe(const A4 &u, const A4 &DV, int i, int j, const UVPar &g)
+{
+    if (g.uv_c2) return 0.25 * (DV(i, j, 0) + DV(i - 1, j, 0)) * (u(i, j, 0) + u(i, j - 1, 0));
+    const double umm = u(i, j - 2, 0), um = u(i, j - 1, 0), u0 = u(i, j, 0), up = u(i, j + 1, 0);
+    const double hmm = DV(i - 2, j, 0), hm = DV(i - 1, j, 0), h0 = DV(i, j, 0), hp = DV(i + 1, j, 0);
+    double uee_j = um - 2.0 * u0 + up, uee_jm1 = umm - 2.0 * um + u0;
+    const double Hvxx_i = hm - 2.0 * h0 + hp, Hvxx_im1 = hmm - 2.0 * hm + h0;
+    if (j == g.dloy && !g.pery) uee_jm1 = uee_j;
+    else if (j == g.dhiy + 1 && !g.pery) uee_j = uee_jm1;
+    const double cff = 1.0 / 6.0;
+    const double cff1 = u0 + um;
+    const double cff2 = h0 + hm;
+    return 0.25 * (cff1 - (uee_j + uee_jm1) * cff) * (cff2 - cff * (Hvxx_i + Hvxx_im1));
+}
+__device__ __forceinline__ double s2_VFx(const A4 &v, const A4 &DU, int i, int j, const UVPar &g)
+{
+    if (g.uv_c2) return 0.25 * (DU(i, j, 0) + DU(i, j - 1, 0)) * (v(i, j, 0) + v(i - 1, j, 0));
+    const double cff = 1.0 / 6.0;
+    const double vmm = v(i - 2, j, 0), vm = v(i - 1, j, 0), v0 = v(i, j, 0), vp = v(i + 1, j, 0);
+    const double hmm = DU(i, j - 2, 0), hm = DU(i, j - 1, 0), h0 = DU(i, j, 0), hp = DU(i, j + 1, 0);
+    double vxx_i = vm - 2.0 * v0 + vp, vxx_im1 = vmm - 2.0 * vm + v0;
+    const double Huee_j = hm - 2.0 * h0 + hp, Huee_jm1 = hmm - 2.0 * hm + h0;
+    if (i == g.dlox && !g.perx) vxx_im1 = vxx_i;
+    else if (i == g.dhix + 1 && !g.perx) vxx_i = vxx_im1;
+    const double cff1 = v0 + vm;
+    const double cff2 = h0 + hm;
+    return 0.25 * (cff1 - (vxx_i + vxx_im1) * cff) * (cff2 - cff * (Huee_j + Huee_jm1));
+}
+__device__ __forceinline__ double s2_VFe(const A4 &v, const A4 &DV, int i, int j, const UVPar &g)
+{
+    if (g.uv_c2) return 0.25 * (DV(i, j, 0) + DV(i, j + 1, 0)) * (v(i, j, 0) + v(i, j + 1, 0));
+    const double vm = v(i, j - 1, 0), v0 = v(i, j, 0), vp = v(i, j + 1, 0), vpp = v(i, j + 2, 0);
+    const double hm = DV(i, j - 1, 0), h0 = DV(i, j, 0), hp = DV(i, j + 1, 0), hpp = DV(i, j + 2, 0);
+    double vee_j = vm - 2.0 * v0 + vp, vee_jp1 = v0 - 2.0 * vp + vpp;
+    double Hvee_j = hm - 2.0 * h0 + hp, Hvee_jp1 = h0 - 2.0 * hp + hpp;
+    if (j == g.dloy && !g.pery) { vee_j = vee_jp1; Hvee_j = Hvee_jp1; }
+    else if (j == g.dhiy && !g.pery) { vee_jp1 = vee_j; Hvee_jp1 = Hvee_j; }
+    const double cff = 1.0 / 6.0;
+    const double cff1 = v0 + vp;
+    return 0.25 * (cff1 - (vee_j + vee_jp1) * cff) * (h0 + hp - cff * (Hvee_j + Hvee_jp1));
+}
+
+__global__ void k2d_uvbar(B3 xb, B3 yb, B3 un, UVPar P, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, A4 vb_stp, A4 ub_new, A4 vb_new,
+                          A4 rubar_rhs, A4 rvbar_rhs, A4 rubar_stp, A4 rvbar_stp, A4 rubar_pts, A4 rvbar_pts,
+                          A4 zeta_stp, A4 h, A4 pm, A4 pn, A4 fcor, A4 rhoA, A4 msku, A4 mskv, A4 mskp, A4 visc2_p, A4 visc2_r,
+                          A4 rufrc, A4 rvfrc, A4 ru2d, A4 rv2d, A4 Drhs, A4 DUon, A4 DVom, A4 Dnew, A4 zwrk, A4 gzeta, A4 gzeta2, A4 gzetaSA)
+{
+    RH_IJ(un);
+    const double cffg = 0.5 * P.g, third = 1.0 / 3.0;
+    if (inb2(xb, i, j)) {
+        // pressure gradient, :479-492
+        const double on_u = 2.0 / (pn(i, j, 0) + pn(i - 1, j, 0));
+        double rhs = cffg * on_u *
+            ((h(i - 1, j, 0) + h(i, j, 0)) * (gzeta(i - 1, j, 0) - gzeta(i, j, 0)) +
+             (h(i - 1, j, 0) - h(i, j, 0)) * (gzetaSA(i - 1, j, 0) + gzetaSA(i, j, 0) +
+                 third * (rhoA(i - 1, j, 0) - rhoA(i, j, 0)) * (zwrk(i - 1, j, 0) - zwrk(i, j, 0))) +
+             (gzeta2(i - 1, j, 0) - gzeta2(i, j, 0)));
+        // advection, rhs_uv_2d :147-153
+        {
+            const double cff1 = s2_UFx(ub_rhs, DUon, i, j, P) - s2_UFx(ub_rhs, DUon, i - 1, j, P);
+            const double cff2 = s2_UFe(ub_rhs, DVom, i, j + 1, P) - s2_UFe(ub_rhs, DVom, i, j, P);
+            rhs -= (cff1 + cff2);
+        }
+        // Coriolis with Hz := Drhs, :530 / REMORA_coriolis.cpp:19-27
+        if (P.use_cor) {
+            const double fm0 = fcor(i, j, 0) * (1.0 / (pm(i, j, 0) * pn(i, j, 0))), fm1 = fcor(i - 1, j, 0) * (1.0 / (pm(i - 1, j, 0) * pn(i - 1, j, 0)));
+            const double UFx_i = 0.5 * Drhs(i, j, 0) * fm0 * (vb_rhs(i, j, 0) + vb_rhs(i, j + 1, 0));
+            const double UFx_im1 = 0.5 * Drhs(i - 1, j, 0) * fm1 * (vb_rhs(i - 1, j, 0) + vb_rhs(i - 1, j + 1, 0));
+            rhs += 0.5 * (UFx_i + UFx_im1);
+        }
+        // harmonic viscosity with Hz := Drhs, dt = 0, :536-538 / REMORA_uv3dmix.cpp:48-90 (the u += 0*... update is a no-op)
+        {
+            const MixR r0 = mix_r_metrics(pm, pn, visc2_r, i, j), r1 = mix_r_metrics(pm, pn, visc2_r, i - 1, j);
+            const MixP p0 = mix_p_metrics(pm, pn, visc2_p, mskp, i, j), p1 = mix_p_metrics(pm, pn, visc2_p, mskp, i, j + 1);
+            const double UFx0 = r0.on_r * r0.on_r * r0.visc * mix_r_cff(r0, Drhs, ub_rhs, vb_rhs, i, j, 0);
+            const double UFx1 = r1.on_r * r1.on_r * r1.visc * mix_r_cff(r1, Drhs, ub_rhs, vb_rhs, i - 1, j, 0);
+            const double UFe0 = p0.om_p * p0.om_p * p0.visc * mix_p_cff(p0, Drhs, ub_rhs, vb_rhs, i, j, 0);
+            const double UFe1 = p1.om_p * p1.om_p * p1.visc * mix_p_cff(p1, Drhs, ub_rhs, vb_rhs, i, j + 1, 0);
+            const double cff1 = 0.5 * (pn(i - 1, j, 0) + pn(i, j, 0)) * (UFx0 - UFx1);
+            const double cff2 = 0.5 * (pm(i - 1, j, 0) + pm(i, j, 0)) * (UFe1 - UFe0);
+            rhs += cff1 + cff2;
+        }
+        // coupling with the 3-D forcing, :543-624
+        if (P.couple == 0) rhs += rufrc(i, j, 0);
+        else {
+            double f = rufrc(i, j, 0);
+            if (P.couple == 1) { f -= rhs; rhs += f; ru2d(i, j, 0, 0) = f; }
+            else if (P.couple == 2) {
+                f = f - rhs;
+                const double r0 = ru2d(i, j, 0, 0);
+                rhs = rhs + 1.5 * f - 0.5 * r0;
+                ru2d(i, j, 0, 1) = r0; ru2d(i, j, 0, 0) = f;
+            } else {
+                const double c1 = 23.0 / 12.0, c2 = 16.0 / 12.0, c3 = 5.0 / 12.0;
+                f = f - rhs;
+                const double r0 = ru2d(i, j, 0, 0), r1 = ru2d(i, j, 0, 1);
+                rhs = rhs + c1 * f - c2 * r0 + c3 * r1;
+                ru2d(i, j, 0, 1) = r0; ru2d(i, j, 0, 0) = f;
+            }
+            rufrc(i, j, 0) = f;
+        }
+        // time step, :626-713
+        const double Dstp0 = zeta_stp(i, j, 0) + h(i, j, 0), Dstp1 = zeta_stp(i - 1, j, 0) + h(i - 1, j, 0);
+        const double cff = (pm(i, j, 0) + pm(i - 1, j, 0)) * (pn(i, j, 0) + pn(i - 1, j, 0));
+        const double Dnew_avg = 1.0 / (Dnew(i, j, 0) + Dnew(i - 1, j, 0));
+        if (!P.am3) ub_new(i, j, 0) = (ub_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * msku(i, j, 0);
+        else ub_new(i, j, 0) = (ub_stp(i, j, 0) * (Dstp0 + Dstp1) +
+                                cff * (P.c1 * rhs + P.c2 * rubar_stp(i, j, 0) - P.c3 * rubar_pts(i, j, 0))) * Dnew_avg * msku(i, j, 0);
+        if (P.predictor) rubar_rhs(i, j, 0) = rhs;                             // :721-730
+    }
+    if (inb2(yb, i, j)) {
+        const double om_v = 2.0 / (pm(i, j, 0) + pm(i, j - 1, 0));
+        double rhs = cffg * om_v *
+            ((h(i, j - 1, 0) + h(i, j, 0)) * (gzeta(i, j - 1, 0) - gzeta(i, j, 0)) +
+             (h(i, j - 1, 0) - h(i, j, 0)) * (gzetaSA(i, j - 1, 0) + gzetaSA(i, j, 0) +
+                 third * (rhoA(i, j - 1, 0) - rhoA(i, j, 0)) * (zwrk(i, j - 1, 0) - zwrk(i, j, 0))) +
+             (gzeta2(i, j - 1, 0) - gzeta2(i, j, 0)));
+        {
+            const double cff1 = s2_VFx(vb_rhs, DUon, i + 1, j, P) - s2_VFx(vb_rhs, DUon, i, j, P);
+            const double cff2 = s2_VFe(vb_rhs, DVom, i, j, P) - s2_VFe(vb_rhs, DVom, i, j - 1, P);
+            rhs -= (cff1 + cff2);
+        }
+        if (P.use_cor) {
+            const double fm0 = fcor(i, j, 0) * (1.0 / (pm(i, j, 0) * pn(i, j, 0))), fm1 = fcor(i, j - 1, 0) * (1.0 / (pm(i, j - 1, 0) * pn(i, j - 1, 0)));
+            const double VFe_j = 0.5 * Drhs(i, j, 0) * fm0 * (ub_rhs(i, j, 0) + ub_rhs(i + 1, j, 0));
+            const double VFe_jm1 = 0.5 * Drhs(i, j - 1, 0) * fm1 * (ub_rhs(i, j - 1, 0) + ub_rhs(i + 1, j - 1, 0));
+            rhs -= 0.5 * (VFe_j + VFe_jm1);
+        }
+        {
+            const MixR r0 = mix_r_metrics(pm, pn, visc2_r, i, j), r1 = mix_r_metrics(pm, pn, visc2_r, i, j - 1);
+            const MixP p0 = mix_p_metrics(pm, pn, visc2_p, mskp, i, j), p1 = mix_p_metrics(pm, pn, visc2_p, mskp, i + 1, j);
+            const double VFe0 = r0.om_r * r0.om_r * r0.visc * mix_r_cff(r0, Drhs, ub_rhs, vb_rhs, i, j, 0);
+            const double VFe1 = r1.om_r * r1.om_r * r1.visc * mix_r_cff(r1, Drhs, ub_rhs, vb_rhs, i, j - 1, 0);
+            const double VFx0 = p0.on_p * p0.on_p * p0.visc * mix_p_cff(p0, Drhs, ub_rhs, vb_rhs, i, j, 0);
+            const double VFx1 = p1.on_p * p1.on_p * p1.visc * mix_p_cff(p1, Drhs, ub_rhs, vb_rhs, i + 1, j, 0);
+            const double cff1 = 0.5 * (pn(i, j - 1, 0) + pn(i, j, 0)) * (VFx1 - VFx0);
+            const double cff2 = 0.5 * (pm(i, j - 1, 0) + pm(i, j, 0)) * (VFe0 - VFe1);
+            rhs += cff1 - cff2;
+        }
+        if (P.couple == 0) rhs += rvfrc(i, j, 0);
+        else {
+            double f = rvfrc(i, j, 0);
+            if (P.couple == 1) { f -= rhs; rhs += f; rv2d(i, j, 0, 0) = f; }
+            else if (P.couple == 2) {
+                f = f - rhs;
+                const double r0 = rv2d(i, j, 0, 0);
+                rhs = rhs + 1.5 * f - 0.5 * r0;
+                rv2d(i, j, 0, 1) = r0; rv2d(i, j, 0, 0) = f;
+            } else {
+                const double c1 = 23.0 / 12.0, c2 = 16.0 / 12.0, c3 = 5.0 / 12.0;
+                f = f - rhs;
+                const double r0 = rv2d(i, j, 0, 0), r1 = rv2d(i, j, 0, 1);
+                rhs = rhs + c1 * f - c2 * r0 + c3 * r1;
+                rv2d(i, j, 0, 1) = r0; rv2d(i, j, 0, 0) = f;
+            }
+            rvfrc(i, j, 0) = f;
+        }
+        const double Dstp0 = zeta_stp(i, j, 0) + h(i, j, 0), Dstp1 = zeta_stp(i, j - 1, 0) + h(i, j - 1, 0);
+        const double cff = (pm(i, j, 0) + pm(i, j - 1, 0)) * (pn(i, j, 0) + pn(i, j - 1, 0));
+        const double Dnew_avg = 1.0 / (Dnew(i, j, 0) + Dnew(i, j - 1, 0));
+        if (!P.am3) vb_new(i, j, 0) = (vb_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mskv(i, j, 0);
+        else vb_new(i, j, 0) = (vb_stp(i, j, 0) * (Dstp0 + Dstp1) +
+                                cff * (P.c1 * rhs + P.c2 * rvbar_stp(i, j, 0) - P.c3 * rvbar_pts(i, j, 0))) * Dnew_avg * mskv(i, j, 0);
+        if (P.predictor) rvbar_rhs(i, j, 0) = rhs;
+    }
+}
+
+// REMORA::rhs_uv_2d as a leaf of its own (REMORA_rhs_uv_2d.cpp:20-238): rhs_ubar, rhs_vbar -= advection
+__global__ void k_rhs_uv_2d(B3 xb, B3 yb, B3 un, UVPar P, A4 ub, A4 vb, A4 rhs_u, A4 rhs_v, A4 DUon, A4 DVom)
+{
+    RH_IJ(un);
+    if (inb2(xb, i, j)) {
+        const double cff1 = s2_UFx(ub, DUon, i, j, P) - s2_UFx(ub, DUon, i - 1, j, P);
+        const double cff2 = s2_UFe(ub, DVom, i, j + 1, P) - s2_UFe(ub, DVom, i, j, P);
+        rhs_u(i, j, 0) -= (cff1 + cff2);
+    }
+    if (inb2(yb, i, j)) {
+        const double cff1 = s2_VFx(vb, DUon, i + 1, j, P) - s2_VFx(vb, DUon, i, j, P);
+        const double cff2 = s2_VFe(vb, DVom, i, j, P) - s2_VFe(vb, DVom, i, j - 1, P);
+        rhs_v(i, j, 0) -= (cff1 + cff2);
+    }
+}
+static UVPar uvpar_base(const rh_ctx *c)
+{
+    UVPar P; memset(&P, 0, sizeof P);
+    P.dlox = c->dom.lo[0]; P.dhix = c->dom.hi[0]; P.dloy = c->dom.lo[1]; P.dhiy = c->dom.hi[1];
+    P.perx = c->prm.periodic[0]; P.pery = c->prm.periodic[1]; P.uv_c2 = c->prm.uv_c2; P.use_cor = c->prm.use_coriolis; P.g = c->prm.g;
+    return P;
+}
+static int need_uv2d_stencil(const rh_box &xb, const rh_box &yb, const rh_array4 &ub, const rh_array4 &vb, const rh_array4 &DUon, const rh_array4 &DVom)
+{
+    rh_box q = bx_grow(xb, 2, 2, 0); RH_NEED(ub, q); q = bx_grow(yb, 2, 2, 0); RH_NEED(vb, q);
+    q = xb; q.lo[0] -= 2; q.hi[0] += 2; RH_NEED(DUon, q); q = xb; q.lo[0] -= 2; q.hi[0] += 1; q.hi[1] += 1; RH_NEED(DVom, q);
+    q = yb; q.lo[1] -= 2; q.hi[1] += 2; RH_NEED(DVom, q); q = yb; q.lo[1] -= 2; q.hi[1] += 1; q.hi[0] += 1; RH_NEED(DUon, q);
+    return 0;
+}
+extern "C" int rh_rhs_uv_2d(rh_ctx *c, rh_box xbx, rh_box ybx, rh_array4 ubar, rh_array4 vbar, rh_array4 rhs_ubar, rh_array4 rhs_vbar,
+                            rh_array4 DUon, rh_array4 DVom, int krhs)
+{
+    TScope t(c, "rhs_uv_2d");
+    xbx = bx_slab(xbx, 2, 0); ybx = bx_slab(ybx, 2, 0);
+    if (krhs < 0 || krhs >= ubar.ncomp || krhs >= vbar.ncomp) return rh_fail("rh_rhs_uv_2d: krhs out of range");
+    const rh_array4 ub = a4_comp(ubar, krhs), vb = a4_comp(vbar, krhs);
+    RH_TRY(need_uv2d_stencil(xbx, ybx, ub, vb, DUon, DVom));
+    RH_NEED(rhs_ubar, xbx); RH_NEED(rhs_vbar, ybx);
+    const rh_box un = bx_union(xbx, ybx);
+    k_rhs_uv_2d<<<grid2(un), rh_block(), 0, c->stream>>>(mkB(xbx), mkB(ybx), mkB(un), uvpar_base(c), mkA(ub), mkA(vb), mkA(rhs_ubar), mkA(rhs_vbar), mkA(DUon), mkA(DVom));
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, int predictor, int first, int my_iif, int *next_indx1)
+{
+    TScope tsc(c, "advance_2d");
+    const int iic = istep, ntfirst = 0;
+    // time indices, :79-101
+    int knew = 3;
+    int krhs = (my_iif + iic) % 2 + 1;
+    int kstp = my_iif <= 1 ? iic % 2 + 1 : (iic % 2 + my_iif % 2 + 1) % 2 + 1;
+    const int indx1 = krhs;
+    if (predictor) *next_indx1 = 3 - indx1;
+    else { knew = *next_indx1; kstp = 3 - knew; krhs = 3; }
+    int ptsk = 3 - kstp;
+    knew -= 1; krhs -= 1; kstp -= 1; ptsk -= 1;
+    if (knew < 0 || knew > 2 || kstp < 0 || kstp > 1 || ptsk < 0 || ptsk > 1) return rh_fail("rh_advance_2d: inconsistent time indices (next_indx1 = %d)", *next_indx1);
+    const int nfast = c->nfast;
+    if (my_iif < 0 || my_iif + 1 > 2 * c->prm.ndtfast) return rh_fail("rh_advance_2d: my_iif out of range");
+    const double *w1 = c->w1.data(), *w2 = c->w2.data();
+
+    const rh_box b2 = bx_slab(c->bx, 2, 0);
+    const rh_box tbxp1 = bx_grow(b2, 1, 1, 0), tbxp3 = bx_grow(b2, 3, 3, 0);
+    const rh_box xgbx2 = bx_grow(bx_nodal(b2, 0), 2, 2, 0), ygbx2 = bx_grow(bx_nodal(b2, 1), 2, 2, 0);
+    const rh_box xbxD = bx_nodal(b2, 0), ybxD = bx_nodal(b2, 1);
+    if (s->zeta.ncomp < 3 || s->ubar.ncomp < 3 || s->vbar.ncomp < 3 || s->rzeta.ncomp < 2 || s->rubar.ncomp < 3 || s->rvbar.ncomp < 3 ||
+        s->ru2d.ncomp < 2 || s->rv2d.ncomp < 2 || s->h.ncomp < 1)
+        return rh_fail("rh_advance_2d: a barotropic array has too few components");
+    if (!predictor && s->rzeta.ncomp < 2) return rh_fail("rh_advance_2d: rzeta");
+
+    const rh_array4 zeta_rhs = a4_comp(s->zeta, krhs), zeta_stp = a4_comp(s->zeta, kstp), zeta_new = a4_comp(s->zeta, knew);
+    const rh_array4 ub_rhs = a4_comp(s->ubar, krhs), vb_rhs = a4_comp(s->vbar, krhs);
+
+    // ---- Drhs, DUon, DVom (:149-166) and their ghost exchange (:170-171)
+    RH_NEED(s->zeta, tbxp3); RH_NEED(s->h, tbxp3); RH_NEED(c->Drhs, tbxp3);
+    RH_NEED(s->ubar, xgbx2); RH_NEED(s->vbar, ygbx2); RH_NEED(c->DUon, xgbx2); RH_NEED(c->DVom, ygbx2);
+    RH_NEED(s->pn, bx_growlo_i(xgbx2)); RH_NEED(s->pm, bx_growlo_j(ygbx2));
+    k2d_flux<<<grid2(tbxp3), rh_block(), 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkA(zeta_rhs), mkA(s->h), mkA(ub_rhs), mkA(vb_rhs),
+        mkA(s->pm), mkA(s->pn), mkA(c->Drhs), mkA(c->DUon), mkA(c->DVom));
+    RH_LAUNCH_CHECK();
+    RH_TRY(halo_fill_boundary(c, mfv(c, c->DUon, 1, 0, 0), 0, 1));
+    RH_TRY(halo_fill_boundary(c, mfv(c, c->DVom, 0, 1, 0), 0, 1));
+
+    // ---- averages + free surface
+    ZetaPar zp; memset(&zp, 0, sizeof zp);
+    zp.predictor = predictor ? 1 : 0; zp.dtfast = dtfast; zp.do_step = my_iif < nfast;
+    if (predictor) {
+        if (first) { zp.avg_mode = 0; zp.wt_b = (-1.0 / 12.0) * w2[my_iif + 1]; }
+        else {
+            if (my_iif < 1) return rh_fail("rh_advance_2d: first_2d_step must be set for my_iif == 0");
+            zp.avg_mode = 1; zp.wt_a = w1[my_iif - 1]; zp.wt_b = (8.0 / 12.0) * w2[my_iif] - (1.0 / 12.0) * w2[my_iif + 1];
+        }
+    } else { zp.avg_mode = 2; zp.wt_b = first ? w2[my_iif] : 5.0 / 12.0 * w2[my_iif]; }
+    zp.zmode = (my_iif == 0) ? 0 : (predictor ? 1 : 2);
+    RH_NEED(s->Zt_avg1, tbxp3); RH_NEED(s->DU_avg1, xgbx2); RH_NEED(s->DU_avg2, xgbx2); RH_NEED(s->DV_avg1, ygbx2); RH_NEED(s->DV_avg2, ygbx2);
+    RH_NEED(s->rzeta, tbxp1); RH_NEED(s->pm, tbxp1); RH_NEED(s->pn, tbxp1); RH_NEED(s->mskr, tbxp1); RH_NEED(s->rhoS, tbxp1); RH_NEED(s->rhoA, tbxp1);
+    RH_NEED(c->Dnew, tbxp1); RH_NEED(c->zwrk, tbxp1); RH_NEED(c->gzeta, tbxp1); RH_NEED(c->gzeta2, tbxp1); RH_NEED(c->gzetaSA, tbxp1);
+    k2d_zeta<<<grid2(tbxp3), rh_block(), 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkB(tbxp1), zp, mkA(zeta_rhs), mkA(zeta_stp), mkA(zeta_new),
+        mkA(a4_comp(s->rzeta, kstp)), mkA(a4_comp(s->rzeta, ptsk)), mkA(a4_comp(s->rzeta, krhs < 2 ? krhs : 0)), mkA(s->h), mkA(s->pm), mkA(s->pn),
+        mkA(s->mskr), mkA(s->rhoS), mkA(s->rhoA), mkA(c->DUon), mkA(c->DVom), mkA(s->Zt_avg1), mkA(s->DU_avg1), mkA(s->DU_avg2), mkA(s->DV_avg1), mkA(s->DV_avg2),
+        mkA(c->Dnew), mkA(c->zwrk), mkA(c->gzeta), mkA(c->gzeta2), mkA(c->gzetaSA));
+    RH_LAUNCH_CHECK();
+    if (my_iif >= nfast) return 0;                                             // :362-363
+
+    // ---- momentum
+    UVPar P = uvpar_base(c);
+    P.predictor = predictor ? 1 : 0;
+    if (first && predictor) P.couple = (iic == ntfirst) ? 1 : (iic == ntfirst + 1 ? 2 : 3); else P.couple = 0;
+    if (my_iif == 0 || predictor) { P.am3 = 0; P.c1 = (my_iif == 0) ? 0.5 * dtfast : dtfast; }
+    else { P.am3 = 1; P.c1 = 0.5 * dtfast * 5.0 / 12.0; P.c2 = 0.5 * dtfast * 8.0 / 12.0; P.c3 = 0.5 * dtfast * 1.0 / 12.0; }
+    RH_TRY(need_uv2d_stencil(xbxD, ybxD, ub_rhs, vb_rhs, c->DUon, c->DVom));
+    {
+        const rh_box un = bx_union(xbxD, ybxD), g1 = bx_grow(un, 1, 1, 0);
+        RH_NEED(s->pm, g1); RH_NEED(s->pn, g1); RH_NEED(s->visc2_r, g1); RH_NEED(s->visc2_p, g1); RH_NEED(s->mskp, g1); RH_NEED(c->Drhs, g1);
+        RH_NEED(s->h, tbxp1); RH_NEED(s->rhoA, tbxp1); RH_NEED(s->zeta, tbxp1);
+        if (c->prm.use_coriolis) RH_NEED(s->fcor, tbxp1);
+        RH_NEED(s->msku, xbxD); RH_NEED(s->mskv, ybxD); RH_NEED(s->rufrc, xbxD); RH_NEED(s->rvfrc, ybxD); RH_NEED(s->ru2d, xbxD); RH_NEED(s->rv2d, ybxD);
+        RH_NEED(s->rubar, xbxD); RH_NEED(s->rvbar, ybxD); RH_NEED(s->ubar, xbxD); RH_NEED(s->vbar, ybxD);
+        // rubar/rvbar(krhs) only exist for the predictor (krhs < 2); the corrector never writes them
+        const int kr = krhs < 2 ? krhs : 0;
+        k2d_uvbar<<<grid2(un), rh_block(), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), P, mkA(ub_rhs), mkA(vb_rhs),
+            mkA(a4_comp(s->ubar, kstp)), mkA(a4_comp(s->vbar, kstp)), mkA(a4_comp(s->ubar, knew)), mkA(a4_comp(s->vbar, knew)),
+            mkA(a4_comp(s->rubar, kr)), mkA(a4_comp(s->rvbar, kr)), mkA(a4_comp(s->rubar, kstp)), mkA(a4_comp(s->rvbar, kstp)),
+            mkA(a4_comp(s->rubar, ptsk)), mkA(a4_comp(s->rvbar, ptsk)),
+            mkA(zeta_stp), mkA(s->h), mkA(s->pm), mkA(s->pn), mkA(s->fcor), mkA(s->rhoA), mkA(s->msku), mkA(s->mskv), mkA(s->mskp),
+            mkA(s->visc2_p), mkA(s->visc2_r), mkA(s->rufrc), mkA(s->rvfrc), mkA(s->ru2d), mkA(s->rv2d),
+            mkA(c->Drhs), mkA(c->DUon), mkA(c->DVom), mkA(c->Dnew), mkA(c->zwrk), mkA(c->gzeta), mkA(c->gzeta2), mkA(c->gzetaSA));
+        RH_LAUNCH_CHECK();
+    }
+    // ---- ghost cells of the new time level, :735-755
+    RH_TRY(halo_fillpatch(c, mfv(c, s->ubar, 1, 0, 0), s->msku, RH_BCV_UBAR, knew, 1));
+    RH_TRY(halo_fillpatch(c, mfv(c, s->vbar, 0, 1, 0), s->mskv, RH_BCV_VBAR, knew, 1));
+    RH_TRY(halo_fillpatch(c, mfv(c, s->zeta, 0, 0, 0), s->mskr, RH_BCV_ZETA, knew, 1));
+    return 0;
+}
+
+// REMORA::advance_2d_onestep, REMORA_advance_2d_onestep.cpp:6-53
+extern "C" int rh_advance_2d_onestep(rh_ctx *c, rh_state *s, int istep, int my_iif)
+{
+    const int nfast_counter = c->nfast + 1;
+    const double dtfast = c->prm.dt / (double)c->prm.ndtfast;
+    const int first = (my_iif == 0);
+    int next_indx1 = 0;
+    RH_TRY(rh_advance_2d(c, s, istep, dtfast, 1, first, my_iif, &next_indx1));
+    if (my_iif < nfast_counter - 1) RH_TRY(rh_advance_2d(c, s, istep, dtfast, 0, first, my_iif, &next_indx1));
+    return 0;
+}

@@ -1,0 +1,193 @@
+"""Host-side mirror of the slice of `class REMORA` that drives the TimeIntegration hot path.
+
+Names follow the reference (Source/REMORA.H:357-451, Source/REMORA.cpp:139-212, TimeIntegration/REMORA_TimeStep.cpp:9-66):
+`InitData`, `Evolve`, `timeStep`, `Advance`, `setup_step`, `advance_2d_onestep`, `advance_3d_ml`.  All numerics run in the HIP
+library behind include/remora_hip.h; torch only owns the device buffer (one block per rank, carved by rh_state_bind) and the
+process group.  There is no CPU fallback: without a GPU and the built library every entry point raises.
+"""
+import ctypes as C
+import json
+
+import numpy as np
+
+from . import lib as L
+from .cases import PROB
+
+
+def make_params(case, box=None, nranks=(1, 1), rank_xy=(0, 0)):
+    """rh_params from a case dict (remora_amd/cases.py)."""
+    p = L.Params()
+    nx, ny, nz = case["ncell"]
+    for d, n in enumerate((nx, ny, nz)):
+        p.domain_lo[d] = 0
+        p.domain_hi[d] = n - 1
+    lo, hi = box if box is not None else ((0, 0, 0), (nx - 1, ny - 1, nz - 1))
+    for d in range(3):
+        p.box_lo[d] = lo[d]
+        p.box_hi[d] = hi[d]
+        p.prob_lo[d] = case["prob_lo"][d]
+        p.prob_hi[d] = case["prob_hi"][d]
+    for d in range(2):
+        p.periodic[d] = case["periodic"][d]
+        p.nranks[d] = nranks[d]
+        p.rank_xy[d] = rank_xy[d]
+    p.dt = case["fixed_dt"]
+    p.ndtfast = case["ndtfast"]
+    for k in ("flat_bathymetry", "tracer_c4", "uv_c2", "use_coriolis", "use_prestep", "use_uv3dmix", "use_barotropic", "use_salt",
+              "g", "rho0", "R0", "T0", "S0", "Tcoef", "Scoef", "theta_s", "theta_b", "tcline"):
+        setattr(p, k, case[k])
+    prob = case["prob"]
+    # init_custom_vmix / init_custom_smflux of Exec/<case>/prob.cpp
+    if prob in ("Upwelling", "Advection"):
+        p.vmix_mode = L.VMIX_UPWELLING
+    else:
+        p.vmix_mode = L.VMIX_CONST
+        akv, akt = {"Seamount": (1.0e-5, 1.0e-6), "DoubleGyre": (1.0, 1.0)}[prob]
+        p.Akv_const = akv
+        p.Akt_const[0] = akt
+        p.Akt_const[1] = akt
+        p.Akt_const[2] = 0.0
+    p.smflux_mode = {"Upwelling": L.SMFLUX_UPWELLING, "Seamount": L.SMFLUX_NONE, "Advection": L.SMFLUX_NONE,
+                     "DoubleGyre": L.SMFLUX_FIXED}[prob]
+    p.masks_all_one = 1
+    return p
+
+
+def make_init_params(case):
+    ip = L.InitParams()
+    ip.prob = PROB[case["prob"]]
+    ip.rdrag = case["rdrag"]
+    ip.coriolis_f0 = case["coriolis_f0"]
+    ip.coriolis_beta = case["coriolis_beta"]
+    ip.hmix_constant = case["hmix_constant"]
+    ip.visc2 = case["visc2"]
+    for n in range(L.NCONS):
+        ip.tnu2[n] = case["tnu2"][n]
+    ip.u_0 = case["u_0"]
+    ip.v_0 = case["v_0"]
+    return ip
+
+
+class REMORA:
+    """One level, one box per rank (max_level = 0), fixed dt: the configuration of every pinned case."""
+
+    def __init__(self, case, device="cuda:0", box=None, nranks=(1, 1), rank_xy=(0, 0), stream=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise L.RemoraHipError("REMORA needs a HIP device; this package has no CPU path")
+        self.torch = torch
+        self.lib = L.load()
+        self.case = case
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.params = make_params(case, box, nranks, rank_xy)
+        self.ctx = C.c_void_p()
+        self.stream = stream
+        L.check(self.lib.rh_create(C.byref(self.params), C.c_void_p(stream.cuda_stream if stream is not None else 0), C.byref(self.ctx)))
+        nbytes = self.lib.rh_state_bytes(self.ctx)
+        self.buf = torch.zeros(nbytes // 8 + 32, dtype=torch.float64, device=self.device)
+        base = (self.buf.data_ptr() + 255) // 256 * 256
+        self._base_off = (base - self.buf.data_ptr()) // 8
+        self.state = L.State()
+        L.check(self.lib.rh_state_bind(self.ctx, C.c_void_p(base), C.byref(self.state)))
+        self.istep = 0
+        self.dt = float(case["fixed_dt"])
+        self.t_new = 0.0
+        self.t_old = -1.0e200
+        self.nfast = self.lib.rh_nfast(self.ctx)
+        self.ncell = tuple(case["ncell"])
+        torch.cuda.synchronize(self.device)
+
+    def close(self):
+        if getattr(self, "ctx", None) is not None and self.ctx:
+            self.lib.rh_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- field access (tests, diagnostics) ------------------------------------------------------------------
+    def view(self, name):
+        """torch view [comp, k, j, i] on the device array of a state field, plus its (lo, hi)."""
+        a = getattr(self.state, name)
+        off = (a.p - self.buf.data_ptr()) // 8
+        return self.buf[off:off + a.size].view(a.shape), tuple(a.lo), tuple(a.hi)
+
+    def get(self, name):
+        v, lo, hi = self.view(name)
+        return v.cpu().numpy(), lo, hi
+
+    def set(self, name, arr, lo=None):
+        """Upload a host array [comp, k, j, i]; `lo` = index of arr[...,0,0,0] (default: the device array's lo)."""
+        v, vlo, vhi = self.view(name)
+        t = self.torch.as_tensor(np.ascontiguousarray(arr), dtype=self.torch.float64)
+        if lo is None:
+            lo = vlo
+        o = [lo[d] - vlo[d] for d in range(3)]
+        nc, nk, nj, ni = t.shape
+        v[:nc, o[2]:o[2] + nk, o[1]:o[1] + nj, o[0]:o[0] + ni] = t.to(self.device)
+
+    # ---- REMORA call surface ----------------------------------------------------------------------------------
+    def InitData(self):
+        """REMORA::InitData for the analytic problem of the case (Source/REMORA.cpp:246-342)."""
+        ip = make_init_params(self.case)
+        L.check(self.lib.rh_init_state(self.ctx, C.byref(self.state), C.byref(ip)))
+
+    def begin_step(self):
+        """Head of REMORA::timeStep (REMORA_TimeStep.cpp:48-61): advance the clock, swap old and new."""
+        self.t_old = self.t_new
+        self.t_new += self.dt
+        self.lib.rh_swap_old_new(C.byref(self.state))
+
+    def end_step(self):
+        self.istep += 1
+
+    def setup_step(self):
+        L.check(self.lib.rh_setup_step(self.ctx, C.byref(self.state), self.istep, self.t_old))
+
+    def advance_2d_onestep(self, my_iif):
+        L.check(self.lib.rh_advance_2d_onestep(self.ctx, C.byref(self.state), self.istep, my_iif))
+
+    def advance_3d_ml(self):
+        L.check(self.lib.rh_advance_3d_ml(self.ctx, C.byref(self.state), self.istep))
+
+    def Advance(self):
+        """REMORA::Advance (REMORA_Advance.cpp:7-35)."""
+        L.check(self.lib.rh_advance(self.ctx, C.byref(self.state), self.istep, self.t_old))
+
+    def timeStep(self):
+        self.begin_step()
+        self.Advance()
+        self.end_step()
+
+    def Evolve(self, nsteps):
+        for _ in range(nsteps):
+            self.timeStep()
+
+    def sync(self):
+        L.check(self.lib.rh_sync(self.ctx))
+
+    def plot(self, with_scalar=False):
+        """Plotfile variables [comp, k, j, i] on the valid box (IO/REMORA_Plotfile.cpp:185-235)."""
+        lo = [self.params.box_lo[d] for d in range(3)]
+        hi = [self.params.box_hi[d] for d in range(3)]
+        shp = (6 if with_scalar else 5, hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1)
+        out = self.torch.empty(shp, dtype=self.torch.float64, device=self.device)
+        L.check(self.lib.rh_plot_vars(self.ctx, C.byref(self.state), int(with_scalar), C.c_void_p(out.data_ptr())))
+        self.sync()
+        return out.cpu().numpy()
+
+    # ---- per-kernel timing ---------------------------------------------------------------------------------
+    def timing(self, on=True):
+        L.check(self.lib.rh_timing_enable(self.ctx, int(on)))
+
+    def timing_reset(self):
+        L.check(self.lib.rh_timing_reset(self.ctx))
+
+    def timing_report(self):
+        buf = C.create_string_buffer(1 << 16)
+        L.check(self.lib.rh_timing_report(self.ctx, buf, len(buf)))
+        return json.loads(buf.value.decode())
