@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py -- 3D baroclinic cell-updates/s of the REMORA hot path on N MI355X (one process per GPU).
+
+A "step" is one full REMORA::Advance (setup_step + the barotropic sub-steps + advance_3d_ml, ghost exchange included)
+of the DoubleGyre physics (Exec/DoubleGyre, Tests/test_files/DoubleGyre/DoubleGyre.i) on a 2048 x 2048 x 50 block per GPU
+(BASELINE.json configs[3]).  With N > 1 the domain is 2048 x (2048 N) x 50, split into N j-slabs
+(weak scaling), and every FillBoundary becomes an RCCL send/recv with the two slab neighbours.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- the dominant kernel group of the step, measured live with HIP events on the library's stream
+  cpu_baseline -- the CPU oracle (oracle/, a single-threaded restatement of the reference's path) timed on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
+
+# Algorithmic bytes per cell per launch of each kernel group (8 B x distinct 3-D field components
+# read + written, each counted once; 2-D arrays ignored).
+ALGO_DOUBLES = {
+    "rhs_t_3d": 6 + 1,             # sstore, t, Huon, Hvom, Hz, W -> t
+    "prestep_t": 7 + 2,            # told, tnew, Hz, Huon, Hvom, W(k), (W k+1 shared) -> sstore, tnew
+    "rhs_uv_3d": 8 + 2,            # uold, vold, ru, rv, Huon, Hvom, W, Hz -> ru, rv
+    "uv3dmix": 5 + 2,              # uold, vold, Hz, u, v -> u, v
+    "vert_visc_3d": 3 + 1,         # phi, Hz, Akv -> phi
+    "vert_mean_3d": 2 + 1,
+    "update_massflux_3d": 3 + 2,   # phi, Hz, Hphi -> Hphi (+phi at boundary faces only)
+    "prsgrd": 4 + 2,               # rho, z_r, Hz, (z_w top only) + P scratch -> ru, rv
+    "rho_eos": 4 + 2,              # T, S, Hz, z_r -> rho, bvf
+    "omega": 2 + 1,
+    "t3dmix": 3 + 1,
+    "prestep_uv": 3 + 2,
+    "uv_ab3": 5 + 2,
+    "stretch_transform": 0 + 3,
+    "massflux_old": 3 + 2,
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nx", type=int, default=2048)
+    ap.add_argument("--ny", type=int, default=2048, help="cells in j PER GPU")
+    ap.add_argument("--nz", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=str, default="192x192x50x2", help="nx x ny x nz x steps of the CPU-oracle sample")
+    return ap.parse_args()
+
+
+def bench_case(nx, ny_per_gpu, nz, ngpu):
+    from remora_amd import cases
+    c = cases.get("DoubleGyre")
+    base = c["ncell"]
+    ny = ny_per_gpu * ngpu
+    # same physical x extent; y extent grows with the GPU count so dy (and the work per GPU) is fixed
+    c["prob_hi"] = (c["prob_hi"][0], c["prob_hi"][1] * ngpu, c["prob_hi"][2])
+    c["ncell"] = (nx, ny, nz)
+    c["fixed_dt"] = float(c["fixed_dt"] * min(base[0] / nx, base[1] / ny_per_gpu))    # CFL scaling
+    return c
+
+
+def cpu_baseline(sample):
+    """Time the CPU oracle on a small DoubleGyre grid (same physics, same step)."""
+    from oracle.oracle_py import Oracle
+    nx, ny, nz, steps = (int(x) for x in sample.split("x"))
+    c = bench_case(nx, ny, nz, 1)
+    o = Oracle(c)
+    o.advance(1)                      # first step (iic = 0 branches) not timed
+    t0 = time.perf_counter()
+    o.advance(steps)
+    dt = time.perf_counter() - t0
+    o.close()
+    return {"value": nx * ny * nz * steps / dt, "unit": "cell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"DoubleGyre physics {nx}x{ny}x{nz}, {steps} steps after 1 untimed, oracle/ (serial C restatement, -O2)"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+
+    from remora_amd.model import REMORA
+    case = bench_case(a.nx, a.ny, a.nz, world)
+    nx, ny, nz = case["ncell"]
+    box = ((0, rank * a.ny, 0), (nx - 1, (rank + 1) * a.ny - 1, nz - 1))
+    rem = REMORA(case, device=f"cuda:{local}", box=box, nranks=(1, world), rank_xy=(0, rank))
+    if world > 1:
+        rem.comm_init(dist)
+    rem.InitData()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        rem.timeStep()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        rem.timeStep()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    # sanity: the fields must still be finite (an invalid run must not produce a number)
+    chk = rem.view("cons_new")[0]
+    finite = bool(torch.isfinite(chk).all().item())
+
+    # per-kernel-group timing (HIP events on the library's stream), 2 further steps
+    rem.timing(True)
+    rem.timing_reset()
+    nprof = 2
+    for _ in range(nprof):
+        rem.timeStep()
+    rep = rem.timing_report()
+    rem.timing(False)
+
+    cells_per_gpu = nx * a.ny * nz
+    roof = None
+    leaf = {k: v for k, v in rep.items() if k in ALGO_DOUBLES}
+    if leaf:
+        dom = max(leaf, key=lambda k: leaf[k]["ms"])
+        avg_ms = leaf[dom]["ms"] / leaf[dom]["calls"]
+        bytes_launch = ALGO_DOUBLES[dom] * 8 * cells_per_gpu
+        ach = bytes_launch / (avg_ms * 1e-3) / 1e9
+        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                "share_of_step": leaf[dom]["ms"] / nprof / (el / a.steps * 1e3)}
+    if rank == 0:
+        out = {"metric": "3D baroclinic cell-updates/s", "value": cells_per_gpu * world * a.steps / el, "unit": "cell-updates/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"DoubleGyre physics, {nx}x{a.ny}x{nz} cells per GPU (domain {nx}x{ny}x{nz}), "
+                                      f"dt {case['fixed_dt']:.3f} s, ndtfast {case['ndtfast']}, nfast {rem.nfast}, "
+                                      f"{'j-slab decomposition over RCCL' if world > 1 else 'single box'}",
+                          "parallelism": f"ij-decomp 1x{world}"},
+               "finite": finite,
+               "roofline": roof,
+               "kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])},
+               "algorithmic_hbm_frac_step": (1232.0 * cells_per_gpu / (el / a.steps)) / 1e9 / HBM_PEAK_GBS}
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
+        if not finite:
+            out["value"] = 0.0
+            out["error"] = "non-finite field after the timed steps"
+        print(json.dumps(out), flush=True)
+    rem.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
