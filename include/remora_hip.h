@@ -91,6 +91,27 @@ int  rh_state_bind(const rh_ctx *ctx, void *device_base, rh_state *out);
 int  rh_comm_unique_id(void *id128);
 int  rh_comm_init(rh_ctx *ctx, const void *id128, int rank, int nranks);
 
+/* Transport hook: replaces the built-in RCCL send/recv pair of the ghost exchange, for hosts that own their communicator
+ * (REMORA itself: AMReX ParallelDescriptor / GPU-aware MPI) and for tests (gloo).  Called once per exchange with DEVICE
+ * buffers that are ready on `stream`: send n_lo doubles from send_lo to rank peer_lo and receive n_lo doubles from it into
+ * recv_lo, likewise for the upper neighbour; a peer of -1 means no neighbour on that side.  The block sent to the lower
+ * neighbour is what that neighbour receives from its upper one.  On return the receive buffers must be complete on `stream`.
+ * Return 0 on success. */
+typedef int (*rh_exchange_fn)(void *user, const double *send_lo, double *recv_lo, long n_lo, int peer_lo,
+                              const double *send_hi, double *recv_hi, long n_hi, int peer_hi, void *stream);
+int  rh_comm_set_exchange(rh_ctx *ctx, rh_exchange_fn fn, void *user, int rank, int nranks);
+
+/* Rows a rank exchanges with its j-neighbours for one array (host-only, needs no device): the geometry behind
+ * rh_fill_boundary in a j-slab decomposition (nranks = {1, P}).  arr_lo/arr_hi = the array's grown box, ng = its ghost widths. */
+typedef struct rh_halo_plan {
+    int peer_lo, peer_hi;        /* rank of the lower / upper j-neighbour, -1 = none (domain edge, not periodic) */
+    int nrows;                   /* ghost rows exchanged on each side */
+    int i_lo, i_hi;              /* i-range of every row sent and received (x ghost columns only if x is periodic) */
+    int send_lo_j, send_hi_j;    /* first row of the block sent to the lower / to the upper neighbour */
+    int recv_lo_j, recv_hi_j;    /* first row of the ghost block received from the lower / from the upper neighbour */
+} rh_halo_plan;
+int  rh_halo_plan_j(const rh_params *prm, const int arr_lo[3], const int arr_hi[3], const int ng[3], rh_halo_plan *out);
+
 /* ---- ghost cells ----------------------------------------------------------------------------------- */
 /* amrex::FabArray::FillBoundary(periodicity) for comps [icomp,icomp+ncomp): periodic wrap and, across ranks,
  * neighbour exchange (call sites: SURVEY.md section 2.4).  valid = a's box shrunk by ng. */

@@ -48,3 +48,41 @@ extern "C" int rh_comm_init(rh_ctx *c, const void *id128, int rank, int nranks)
     c->comm = comm; c->rank = rank; c->nranks = nranks;
     return 0;
 }
+
+extern "C" int rh_comm_set_exchange(rh_ctx *c, rh_exchange_fn fn, void *user, int rank, int nranks)
+{
+    if (!c) return rh_fail("rh_comm_set_exchange: null context");
+    if (nranks != c->prm.nranks[0] * c->prm.nranks[1]) return rh_fail("rh_comm_set_exchange: nranks %d does not match the %d x %d process grid", nranks, c->prm.nranks[0], c->prm.nranks[1]);
+    if (rank != c->prm.rank_xy[1] * c->prm.nranks[0] + c->prm.rank_xy[0]) return rh_fail("rh_comm_set_exchange: rank %d is not at (%d,%d) of the process grid", rank, c->prm.rank_xy[0], c->prm.rank_xy[1]);
+    c->xfn = fn; c->xuser = user; c->rank = rank; c->nranks = nranks;
+    return 0;
+}
+
+void comm_release(rh_ctx *c)
+{
+    if (c->comm && g_rccl.CommDestroy) { (void)g_rccl.CommDestroy((ncclComm_t)c->comm); c->comm = nullptr; }
+}
+
+// One ghost exchange: the four message slots of c->d_xbuf, on c->stream.  Sends go out in the order (lower, upper) and
+// receives are posted in the order (upper, lower): with two ranks and a periodic direction both neighbours are the same
+// peer, and the block sent "down" is the one the peer receives "from above" (messages to one peer match in order).
+int comm_exchange(rh_ctx *c, long n_lo, int peer_lo, long n_hi, int peer_hi)
+{
+    double *s_lo = c->d_xbuf, *s_hi = c->d_xbuf + c->xcap, *r_lo = c->d_xbuf + 2 * c->xcap, *r_hi = c->d_xbuf + 3 * c->xcap;
+    if (c->xfn) {
+        const int r = c->xfn(c->xuser, s_lo, r_lo, n_lo, n_lo > 0 ? peer_lo : -1, s_hi, r_hi, n_hi, n_hi > 0 ? peer_hi : -1, (void *)c->stream);
+        if (r != 0) return rh_fail("ghost exchange: transport hook returned %d", r);
+        return 0;
+    }
+    if (!c->comm) return rh_fail("ghost exchange: no communicator");
+    ncclComm_t comm = (ncclComm_t)c->comm;
+#define RH_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return rh_fail("%s failed: %s", #x, g_rccl.GetErrorString(r_)); } while (0)
+    RH_NCCL(g_rccl.GroupStart());
+    if (n_lo > 0) RH_NCCL(g_rccl.Send(s_lo, (size_t)n_lo, ncclDouble, peer_lo, comm, c->stream));
+    if (n_hi > 0) RH_NCCL(g_rccl.Send(s_hi, (size_t)n_hi, ncclDouble, peer_hi, comm, c->stream));
+    if (n_hi > 0) RH_NCCL(g_rccl.Recv(r_hi, (size_t)n_hi, ncclDouble, peer_hi, comm, c->stream));
+    if (n_lo > 0) RH_NCCL(g_rccl.Recv(r_lo, (size_t)n_lo, ncclDouble, peer_lo, comm, c->stream));
+    RH_NCCL(g_rccl.GroupEnd());
+#undef RH_NCCL
+    return 0;
+}

@@ -94,6 +94,8 @@ struct rh_ctx {
     double *d_work = nullptr; long work_bytes = 0;
     // RCCL
     void *comm = nullptr; int rank = 0, nranks = 1;
+    rh_exchange_fn xfn = nullptr; void *xuser = nullptr;      // transport of the ghost exchange (RCCL by default)
+    double *d_xbuf = nullptr; long xcap = 0;                   // 4 message slots: send_lo, send_hi, recv_lo, recv_hi (xcap doubles each)
     // per-kernel-group timing
     bool timing = false;
     std::vector<std::string> tnames; std::map<std::string,int> tslot;
@@ -122,6 +124,8 @@ int  launch_vmix(rh_ctx *c, rh_state *s);
 int  launch_set_zeta(rh_ctx *c, rh_state *s);
 int  launch_uv_ab3(rh_ctx *c, rh_state *s, int istep);
 int  launch_mask_cons(rh_ctx *c, rh_state *s);
+void comm_release(rh_ctx *c);                                   // rh_comm.hip
+int  comm_exchange(rh_ctx *c, long n_lo, int peer_lo, long n_hi, int peer_hi);   // d_xbuf slots, on c->stream
 // small utilities (rh_ctx.hip)
 int  dev_setval(rh_ctx *c, const rh_array4 &a, int icomp, int ncomp, double v);
 int  dev_copy(rh_ctx *c, const rh_array4 &dst, const rh_array4 &src);

@@ -276,8 +276,18 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     if (c->bx.lo[2] != c->dom.lo[2] || c->bx.hi[2] != c->dom.hi[2]) return bad("boxes must span the full vertical (main.cpp:21-23)");
     if (!bx_contains(c->dom, c->bx)) return bad("box outside domain");
     if (prm->ndtfast < 1) return bad("ndtfast < 1");
-    if (!(c->bx.lo[0] == c->dom.lo[0] && c->bx.hi[0] == c->dom.hi[0] && c->bx.lo[1] == c->dom.lo[1] && c->bx.hi[1] == c->dom.hi[1]))
-        return bad("i-j decomposed boxes need rh_comm_init (not available in this build): box must equal the domain");
+    {
+        // j-slab decomposition: every rank owns the full i extent and a contiguous block of rows
+        const int P = prm->nranks[1] < 1 ? 1 : prm->nranks[1], r = prm->rank_xy[1];
+        if (prm->nranks[0] > 1) return bad("only j-slab decompositions (nranks = {1, P}) are implemented");
+        if (c->bx.lo[0] != c->dom.lo[0] || c->bx.hi[0] != c->dom.hi[0]) return bad("a rank must own the full i extent");
+        if (r < 0 || r >= P) return bad("rank_xy[1] outside the process grid");
+        if (P == 1 && (c->bx.lo[1] != c->dom.lo[1] || c->bx.hi[1] != c->dom.hi[1])) return bad("a single rank must own the whole domain");
+        if (P > 1) {
+            if ((r == 0) != (c->bx.lo[1] == c->dom.lo[1]) || (r == P - 1) != (c->bx.hi[1] == c->dom.hi[1])) return bad("box_lo/box_hi inconsistent with rank_xy");
+            if (c->bx.hi[1] - c->bx.lo[1] + 1 < 4) return bad("a slab must be at least 4 rows thick (ghost width 3 + shared face)");
+        }
+    }
     for (int d = 0; d < 2; d++) if (prm->periodic[d] && (c->dom.hi[d] - c->dom.lo[d] + 1) < 4) return bad("periodic direction shorter than the ghost width");
     c->nfast = set_weights(prm->ndtfast, c->w1, c->w2);
     init_bcs(c);
@@ -323,7 +333,8 @@ extern "C" int rh_destroy(rh_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &v : c->tev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &e : c->evpool) (void)hipEventDestroy(e);
-    (void)hipFree(c->d_sc); (void)hipFree(c->d_work);
+    (void)hipFree(c->d_sc); (void)hipFree(c->d_work); if (c->d_xbuf) (void)hipFree(c->d_xbuf);
+    comm_release(c);
     delete c;
     return 0;
 }

@@ -46,20 +46,83 @@ __global__ void k_fill_periodic(A4 a, B3 v, int icomp, int ncomp, int perx, int 
     }
 }
 
+// ---- j-slab decomposition: rows exchanged with the lower / upper neighbour -------------------------------------
+// Geometry only (host, no device).  With an index type that is nodal in j the top valid row (hi_j + 1) is shared with the
+// upper neighbour and is not exchanged: FillBoundary fills ghost points only.
+static int plan_j(const rh_params &P, const int alo[3], const int ahi[3], const int ng[3], rh_halo_plan *o)
+{
+    const int np = P.nranks[1] < 1 ? 1 : P.nranks[1], r = P.rank_xy[1];
+    const int vlo = alo[1] + ng[1], vhi = ahi[1] - ng[1];                       // valid rows of this array
+    const int iy = (vhi - vlo) - (P.box_hi[1] - P.box_lo[1]);                   // 1 if nodal in j
+    if (iy != 0 && iy != 1) return rh_fail("halo plan: array rows [%d,%d] with ghost width %d do not match the rank's box rows [%d,%d]", alo[1], ahi[1], ng[1], P.box_lo[1], P.box_hi[1]);
+    if (vlo != P.box_lo[1]) return rh_fail("halo plan: array does not start at the rank's first row");
+    o->nrows = ng[1];
+    o->peer_lo = (r > 0) ? r - 1 : (P.periodic[1] ? np - 1 : -1);
+    o->peer_hi = (r < np - 1) ? r + 1 : (P.periodic[1] ? 0 : -1);
+    if (np == 1) { o->peer_lo = o->peer_hi = -1; }                              // a single rank wraps locally
+    if (P.periodic[0]) { o->i_lo = alo[0]; o->i_hi = ahi[0]; } else { o->i_lo = alo[0] + ng[0]; o->i_hi = ahi[0] - ng[0]; }
+    o->recv_lo_j = vlo - ng[1];            o->recv_hi_j = vhi + 1;
+    o->send_hi_j = P.box_hi[1] + 1 - ng[1];                                     // the upper neighbour's lower ghost rows
+    o->send_lo_j = P.box_lo[1] + iy;                                            // the lower neighbour's upper ghost rows
+    if (ng[1] > P.box_hi[1] - P.box_lo[1] + 1 - iy) return rh_fail("halo plan: slab thinner than the ghost width");
+    return 0;
+}
+extern "C" int rh_halo_plan_j(const rh_params *prm, const int arr_lo[3], const int arr_hi[3], const int ng[3], rh_halo_plan *out)
+{
+    if (!prm || !out) return rh_fail("rh_halo_plan_j: null argument");
+    return plan_j(*prm, arr_lo, arr_hi, ng, out);
+}
+
+// pack (dir 0) / unpack (dir 1) nrows rows [j0, j0+nrows) x [i0, i1] x all k x ncomp comps; buf is [n][k][row][i]
+__global__ void k_rows(A4 a, double *__restrict__ buf, int dir, int icomp, int ncomp, int i0, int i1, int j0, int nrows)
+{
+    const long w = i1 - i0 + 1; const int nk = a.hi2 - a.lo2 + 1;
+    const long total = w * nrows * nk * ncomp;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        const int i = i0 + (int)(g % w); long r = g / w;
+        const int j = j0 + (int)(r % nrows); r /= nrows;
+        const int k = a.lo2 + (int)(r % nk); const int n = icomp + (int)(r / nk);
+        if (dir == 0) buf[g] = a(i, j, k, n); else a(i, j, k, n) = buf[g];
+    }
+}
+
 int halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp)
 {
-    const int perx = c->prm.periodic[0], pery = c->prm.periodic[1];
-    if (!perx && !pery) return 0;
+    const int np = c->prm.nranks[1] < 1 ? 1 : c->prm.nranks[1];
+    const int perx = c->prm.periodic[0], pery = (np == 1) ? c->prm.periodic[1] : 0;     // decomposed: j handled by the exchange
     if (icomp < 0 || icomp + ncomp > m.a.ncomp) return rh_fail("halo_fill_boundary: component range");
     A4 a = mkA(m.a); B3 v = mkB(m.valid);
     const long NX = a.hi0 - a.lo0 + 1, NY = a.hi1 - a.lo1 + 1, vx = v.hi0 - v.lo0 + 1, vy = v.hi1 - v.lo1 + 1;
     if (vx <= 0 || vy <= 0 || !bx_contains(bx_of(m.a), m.valid)) return rh_fail("halo_fill_boundary: valid box not inside array");
-    const long total = ((NY - vy) * NX + vy * (NX - vx)) * (a.hi2 - a.lo2 + 1) * ncomp;
-    if (total <= 0) return 0;
-    long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
-    k_fill_periodic<<<(int)nb, 256, 0, c->stream>>>(a, v, icomp, ncomp, perx, pery,
-                                                     c->dom.hi[0] - c->dom.lo[0] + 1, c->dom.hi[1] - c->dom.lo[1] + 1);
-    RH_LAUNCH_CHECK();
+    if (perx || pery) {
+        const long total = ((NY - vy) * NX + vy * (NX - vx)) * (a.hi2 - a.lo2 + 1) * ncomp;
+        if (total > 0) {
+            long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
+            k_fill_periodic<<<(int)nb, 256, 0, c->stream>>>(a, v, icomp, ncomp, perx, pery,
+                                                             c->dom.hi[0] - c->dom.lo[0] + 1, c->dom.hi[1] - c->dom.lo[1] + 1);
+            RH_LAUNCH_CHECK();
+        }
+    }
+    if (np == 1) return 0;
+    // ---- neighbour exchange in j (the x wrap above has already filled the x ghost columns of the rows that travel)
+    rh_halo_plan pl;
+    RH_TRY(plan_j(c->prm, m.a.lo, m.a.hi, m.ng, &pl));
+    if (pl.nrows <= 0 || (pl.peer_lo < 0 && pl.peer_hi < 0)) return 0;
+    if (!c->xfn && !c->comm) return rh_fail("halo_fill_boundary: decomposed run without a communicator (call rh_comm_init or rh_comm_set_exchange)");
+    const long w = pl.i_hi - pl.i_lo + 1, n = w * pl.nrows * (a.hi2 - a.lo2 + 1) * ncomp;
+    if (n > c->xcap) {                                                          // grow the message slots (first calls only)
+        RH_HIP(hipStreamSynchronize(c->stream));
+        if (c->d_xbuf) RH_HIP(hipFree(c->d_xbuf));
+        c->xcap = (n + 4095) / 4096 * 4096; c->d_xbuf = nullptr;
+        RH_HIP(hipMalloc((void **)&c->d_xbuf, sizeof(double) * 4 * c->xcap));
+    }
+    double *s_lo = c->d_xbuf, *s_hi = c->d_xbuf + c->xcap, *r_lo = c->d_xbuf + 2 * c->xcap, *r_hi = c->d_xbuf + 3 * c->xcap;
+    long nb = (n + 255) / 256; if (nb > 2048) nb = 2048;
+    if (pl.peer_lo >= 0) { k_rows<<<(int)nb, 256, 0, c->stream>>>(a, s_lo, 0, icomp, ncomp, pl.i_lo, pl.i_hi, pl.send_lo_j, pl.nrows); RH_LAUNCH_CHECK(); }
+    if (pl.peer_hi >= 0) { k_rows<<<(int)nb, 256, 0, c->stream>>>(a, s_hi, 0, icomp, ncomp, pl.i_lo, pl.i_hi, pl.send_hi_j, pl.nrows); RH_LAUNCH_CHECK(); }
+    RH_TRY(comm_exchange(c, pl.peer_lo >= 0 ? n : 0, pl.peer_lo, pl.peer_hi >= 0 ? n : 0, pl.peer_hi));
+    if (pl.peer_lo >= 0) { k_rows<<<(int)nb, 256, 0, c->stream>>>(a, r_lo, 1, icomp, ncomp, pl.i_lo, pl.i_hi, pl.recv_lo_j, pl.nrows); RH_LAUNCH_CHECK(); }
+    if (pl.peer_hi >= 0) { k_rows<<<(int)nb, 256, 0, c->stream>>>(a, r_hi, 1, icomp, ncomp, pl.i_lo, pl.i_hi, pl.recv_hi_j, pl.nrows); RH_LAUNCH_CHECK(); }
     return 0;
 }
 

@@ -70,6 +70,15 @@ class InitParams(C.Structure):
                 ("hmix_constant", C.c_int), ("visc2", C.c_double), ("tnu2", C.c_double * NCONS), ("u_0", C.c_double), ("v_0", C.c_double)]
 
 
+class HaloPlan(C.Structure):
+    _fields_ = [("peer_lo", C.c_int), ("peer_hi", C.c_int), ("nrows", C.c_int), ("i_lo", C.c_int), ("i_hi", C.c_int),
+                ("send_lo_j", C.c_int), ("send_hi_j", C.c_int), ("recv_lo_j", C.c_int), ("recv_hi_j", C.c_int)]
+
+
+# rh_exchange_fn (include/remora_hip.h)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p)
+
+
 class RemoraHipError(RuntimeError):
     pass
 
@@ -91,6 +100,8 @@ SIGNATURES = {
     "rh_state_bind": (C.c_int, [_P, _P, _SP]),
     "rh_comm_unique_id": (C.c_int, [_P]),
     "rh_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "rh_comm_set_exchange": (C.c_int, [_P, EXCHANGE_FN, _P, C.c_int, C.c_int]),
+    "rh_halo_plan_j": (C.c_int, [C.POINTER(Params), C.c_int * 3, C.c_int * 3, C.c_int * 3, C.POINTER(HaloPlan)]),
     "rh_fill_boundary": (C.c_int, [_P, _A, C.c_int * 3, C.c_int, C.c_int]),
     "rh_physbc": (C.c_int, [_P, _A, C.c_int * 3, _A, C.c_int, C.c_int, C.c_int]),
     "rh_fill_patch": (C.c_int, [_P, _A, C.c_int * 3, _A, C.c_int, C.c_int, C.c_int]),

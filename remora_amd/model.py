@@ -109,6 +109,58 @@ class REMORA:
         except Exception:
             pass
 
+    # ---- communicator of a j-slab decomposed run ---------------------------------------------------------------
+    def comm_init(self, dist):
+        """Built-in RCCL transport: rank 0 creates the id, torch.distributed carries the 128 bytes to everyone."""
+        torch = self.torch
+        rank, world = dist.get_rank(), dist.get_world_size()
+        idbuf = (C.c_ubyte * 128)()
+        if rank == 0:
+            L.check(self.lib.rh_comm_unique_id(idbuf))
+        t = torch.tensor(list(idbuf), dtype=torch.uint8)
+        if dist.get_backend() == "nccl":
+            t = t.to(self.device)
+        dist.broadcast(t, src=0)
+        ids = bytes(t.cpu().tolist())
+        L.check(self.lib.rh_comm_init(self.ctx, C.c_char_p(ids), rank, world))
+
+    def comm_set_host_transport(self, dist):
+        """Transport hook that stages every message through the host and torch.distributed send/recv (any backend, e.g.
+        gloo).  For tests of the decomposition on boxes without one GPU per rank; RCCL is the production transport."""
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        torch = self.torch
+
+        def xfn(user, s_lo, r_lo, n_lo, p_lo, s_hi, r_hi, n_hi, p_hi, stream):
+            try:
+                if hip.hipStreamSynchronize(stream) != 0:
+                    return 2
+                reqs, recvs = [], []
+                for sp, n, peer, tag in ((s_lo, n_lo, p_lo, 0), (s_hi, n_hi, p_hi, 1)):      # tag 0: travels down, 1: up
+                    if peer >= 0 and n > 0:
+                        h = torch.empty(n, dtype=torch.float64)
+                        if hip.hipMemcpy(h.data_ptr(), sp, n * 8, 2) != 0:
+                            return 3
+                        reqs.append(dist.isend(h, dst=peer, tag=tag))
+                for rp, n, peer, tag in ((r_hi, n_hi, p_hi, 0), (r_lo, n_lo, p_lo, 1)):      # from above arrives what went down
+                    if peer >= 0 and n > 0:
+                        h = torch.empty(n, dtype=torch.float64)
+                        reqs.append(dist.irecv(h, src=peer, tag=tag))
+                        recvs.append((rp, h, n))
+                for q in reqs:
+                    q.wait()
+                for rp, h, n in recvs:
+                    if hip.hipMemcpy(rp, h.data_ptr(), n * 8, 1) != 0:
+                        return 4
+                return 0
+            except Exception as e:                                      # never let an exception cross the C boundary
+                print("host transport failed:", repr(e), flush=True)
+                return 1
+
+        self._xfn = L.EXCHANGE_FN(xfn)                                  # keep the callback object alive
+        L.check(self.lib.rh_comm_set_exchange(self.ctx, self._xfn, None, dist.get_rank(), dist.get_world_size()))
+
     # ---- field access (tests, diagnostics) ------------------------------------------------------------------
     def view(self, name):
         """torch view [comp, k, j, i] on the device array of a state field, plus its (lo, hi)."""
