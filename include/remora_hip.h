@@ -101,6 +101,10 @@ typedef int (*rh_exchange_fn)(void *user, const double *send_lo, double *recv_lo
                               const double *send_hi, double *recv_hi, long n_hi, int peer_hi, void *stream);
 int  rh_comm_set_exchange(rh_ctx *ctx, rh_exchange_fn fn, void *user, int rank, int nranks);
 
+/* Diagnostic of the active transport: sends two n-double patterns to this rank itself and checks the arrival order.
+ * No counterpart in the reference. */
+int  rh_comm_selftest(rh_ctx *ctx, long n);
+
 /* Rows a rank exchanges with its j-neighbours for one array (host-only, needs no device): the geometry behind
  * rh_fill_boundary in a j-slab decomposition (nranks = {1, P}).  arr_lo/arr_hi = the array's grown box, ng = its ghost widths. */
 typedef struct rh_halo_plan {

@@ -1,6 +1,7 @@
 // rh_adv3d.hip -- device kernels of the corrector half of the baroclinic step (REMORA::advance_3d and its leaves).
 // Same mapping as rh_setup.hip: one thread per (i,j) column, i along the wavefront, k marched in registers.
 #include "rh_common.h"
+#include "rh_tile.h"
 
 // tracer flux helpers (defined in rh_setup.hip; repeated here as the kernels are compiled per translation unit)
 __device__ __forceinline__ double a3_tflux_u3(double t2, double t1, double t0, double tp, double m1, double m0, double mp, double H, double sgn)
@@ -315,6 +316,198 @@ extern "C" int rh_rhs_t_3d(rh_ctx *c, rh_box bx, rh_array4 t, rh_array4 sstore, 
 #undef RH_RT
     RH_LAUNCH_CHECK(); return 0;
 }
+
+// LDS-tiled tracer sweep for all NCONS tracers, shared by the predictor and the corrector:
+//   MODE 0 = prestep_t_advection + tracer prestep_diffusion + t3dmix (arithmetic of k_prestep_t3 in rh_setup.hip)
+//   MODE 1 = rhs_t_3d                                                (arithmetic of k_rhs_t3 above)
+// Per level every thread loads its own point of each field exactly once (the advected field two levels ahead, into a
+// 4-level register window for the vertical flux), the halo ring is fetched by the first threads of the block, and every
+// horizontal neighbour comes from LDS.  One barrier per level (tiles double-buffered on k parity).
+struct TrcPar { int N, flat; double cff, cff1, cff2, dt; int mix_on[RH_NCONS], mix_comp[RH_NCONS], mix_k[RH_NCONS]; };
+
+__device__ __forceinline__ double win_flux_w(double tm1, double t0, double tp1, double tp2, int kk, int N, double w)
+{   // fourth-order vertical flux through face kk from the window t(kk-2), t(kk-1), t(kk), t(kk+1) = tm1, t0, tp1, tp2
+    const double c1 = 0.5, c2 = 7.0 / 12.0, c3 = 1.0 / 12.0;
+    if (kk >= 2 && kk <= N - 1) return (c2 * (t0 + tp1) - c3 * (tm1 + tp2)) * w;
+    if (kk == N + 1) return 0.0;
+    if (kk == N) return (c2 * t0 + c1 * tp1 - c3 * tm1) * w;         // t(N-1)=t0, t(N)=tp1, t(N-2)=tm1
+    if (kk == 1) return (c2 * tp1 + c1 * t0 - c3 * tp2) * w;         // t(1)=tp1, t(0)=t0, t(2)=tp2
+    return 0.0;
+}
+
+template <int MODE, int SCHEME>     // SCHEME: 0 upstream3, 1 centered4, 2 flat-bathymetry centred flux (predictor only)
+__global__ void __launch_bounds__(RT_BX * RT_BY, 2)
+k_tracers_tiled(B3 bx, A4 adv /* cons_old | sstore */, A4 cnew, A4 sst, A4 Hz, A4 Huon, A4 Hvom, A4 W, A4 pm, A4 pn, A4 msku, A4 mskv,
+                A4 diff2, TrcPar P)
+{
+    typedef Tile<2, 2> TT; typedef Tile<1, 0> TU; typedef Tile<0, 1> TV; typedef Tile<1, 1> TH;
+    constexpr int NT = RT_BX * RT_BY;
+    constexpr int SET = RH_NCONS * TT::SIZE + TU::SIZE + TV::SIZE + (MODE == 0 ? TH::SIZE : 0);
+    // k-invariant per-thread values live in LDS, not registers: 8 mask values, and (predictor) 4 mixing coefficients per tracer
+    constexpr int NINV = 8 + (MODE == 0 ? 4 * RH_NCONS : 0);
+    __shared__ double lds[2 * SET + NINV * NT];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
+    double *inv = lds + 2 * SET + tid;                 // inv[q * NT]: conflict-free
+    const int i0 = bx.lo0 + (int)blockIdx.x * RT_BX, j0 = bx.lo1 + (int)blockIdx.y * RT_BY;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool act = inb2(bx, i, j);
+    const int N = P.N;
+    const int ic = act ? i : bx.lo0, jc = act ? j : bx.lo1;     // inactive threads: keep the (unused) own-point loads in bounds
+    const double pm0 = pm(ic, jc, 0), pn0 = pn(ic, jc, 0);
+    const double pmn = (MODE == 0 ? P.cff : P.dt) * pm0 * pn0;
+    const double cmix = P.dt * pm0 * pn0;
+    if (act) {
+        inv[0 * NT] = msku(i - 1, j, 0); inv[1 * NT] = msku(i, j, 0); inv[2 * NT] = msku(i + 1, j, 0); inv[3 * NT] = msku(i + 2, j, 0);
+        inv[4 * NT] = mskv(i, j - 1, 0); inv[5 * NT] = mskv(i, j, 0); inv[6 * NT] = mskv(i, j + 1, 0); inv[7 * NT] = mskv(i, j + 2, 0);
+        if (MODE == 0) {
+            const double pmon_u0 = (pm(i - 1, j, 0) + pm0) / (pn(i - 1, j, 0) + pn0), pmon_u1 = (pm0 + pm(i + 1, j, 0)) / (pn0 + pn(i + 1, j, 0));
+            const double pnom_v0 = (pn(i, j - 1, 0) + pn0) / (pm(i, j - 1, 0) + pm0), pnom_v1 = (pn0 + pn(i, j + 1, 0)) / (pm0 + pm(i, j + 1, 0));
+#pragma unroll
+            for (int n = 0; n < RH_NCONS; n++) {
+                double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+                if (P.mix_on[n]) {
+                    const int dk = P.mix_k[n], dc = P.mix_comp[n];
+                    const double d0 = diff2(i, j, dk, dc);
+                    a0 = 0.25 * (d0 + diff2(i - 1, j, dk, dc)) * pmon_u0; a1 = 0.25 * (diff2(i + 1, j, dk, dc) + d0) * pmon_u1;
+                    b0 = 0.25 * (d0 + diff2(i, j - 1, dk, dc)) * pnom_v0; b1 = 0.25 * (diff2(i, j + 1, dk, dc) + d0) * pnom_v1;
+                }
+                inv[(8 + 4 * n) * NT] = a0; inv[(9 + 4 * n) * NT] = a1; inv[(10 + 4 * n) * NT] = b0; inv[(11 + 4 * n) * NT] = b1;
+            }
+        }
+    }
+    const double sgn = (MODE == 1 && P.flat) ? 1.0 : -1.0;
+    const int c4mode = (MODE == 1 && P.flat) ? 1 : 0;
+    // this thread's halo cell in each tile shape (the three tracer tiles share the geometry of `adv`)
+    const HaloCell ht = halo_cell<2, 2>(adv, i0, j0, tx, ty), hu = halo_cell<1, 0>(Huon, i0, j0, tx, ty),
+                   hv = halo_cell<0, 1>(Hvom, i0, j0, tx, ty), hh = halo_cell<1, 1>(Hz, i0, j0, tx, ty);
+    // per-tracer views, vertical register window t(k-1), t(k), t(k+1), t(k+2), and the values staged for the current level
+    A4 av[RH_NCONS];
+    double wm1[RH_NCONS], w0[RH_NCONS], wp1[RH_NCONS], wp2[RH_NCONS], FCk[RH_NCONS], cn[RH_NCONS], tha[RH_NCONS];
+#pragma unroll
+    for (int n = 0; n < RH_NCONS; n++) {
+        av[n] = adv; av[n].p = adv.p + (long)adv.sn * n;
+        wm1[n] = 0.0; w0[n] = ld_in(av[n], i, j, 0); wp1[n] = ld_in(av[n], i, j, 1); wp2[n] = (2 <= N) ? ld_in(av[n], i, j, 2) : 0.0;
+        FCk[n] = 0.0;
+        cn[n] = act ? cnew(i, j, 0, n) : 0.0;
+        tha[n] = halo_ld(av[n], ht, 0);
+    }
+    double Hu0 = ld_in(Huon, i, j, 0), Hv0 = ld_in(Hvom, i, j, 0), hz = ld_in(Hz, i, j, 0);
+    double uha = halo_ld(Huon, hu, 0), vha = halo_ld(Hvom, hv, 0), hha = (MODE == 0) ? halo_ld(Hz, hh, 0) : 0.0;
+    double Wk = ld_in(W, i, j, 0), Wk1 = ld_in(W, i, j, 1);
+    for (int k = 0; k <= N; k++) {
+        double *set = lds + (k & 1) * SET;
+        double *st[RH_NCONS];
+#pragma unroll
+        for (int n = 0; n < RH_NCONS; n++) { st[n] = set + n * TT::SIZE; tile_put<2, 2>(st[n], tx, ty, w0[n], ht, tha[n]); }
+        double *su = set + RH_NCONS * TT::SIZE, *sv = su + TU::SIZE, *sh = sv + TV::SIZE;
+        tile_put<1, 0>(su, tx, ty, Hu0, hu, uha); tile_put<0, 1>(sv, tx, ty, Hv0, hv, vha);
+        if (MODE == 0) tile_put<1, 1>(sh, tx, ty, hz, hh, hha);
+        // ---- prefetch level k+1 (own points, halo cells, the window's new top level) while level k is computed
+        const bool more = k + 1 <= N;
+        double cn_n[RH_NCONS], tha_n[RH_NCONS], nx2[RH_NCONS];
+#pragma unroll
+        for (int n = 0; n < RH_NCONS; n++) {
+            cn_n[n] = (more && act) ? cnew(i, j, k + 1, n) : 0.0;
+            tha_n[n] = more ? halo_ld(av[n], ht, k + 1) : 0.0;
+            nx2[n] = (k + 3 <= N) ? ld_in(av[n], i, j, k + 3) : 0.0;
+        }
+        const double Hu0_n = more ? ld_in(Huon, i, j, k + 1) : 0.0, Hv0_n = more ? ld_in(Hvom, i, j, k + 1) : 0.0, hz_n = more ? ld_in(Hz, i, j, k + 1) : 0.0;
+        const double uha_n = more ? halo_ld(Huon, hu, k + 1) : 0.0, vha_n = more ? halo_ld(Hvom, hv, k + 1) : 0.0;
+        const double hha_n = (MODE == 0 && more) ? halo_ld(Hz, hh, k + 1) : 0.0;
+        const double Wk2 = more ? ld_in(W, i, j, k + 2) : 0.0;
+        __syncthreads();
+        if (act) {
+            const double Hu1 = su[(ty)*TU::PX + tx + 2], Hv1 = sv[(ty + 2) * TV::PX + tx];
+            const double mu1 = inv[0 * NT], mu0 = inv[1 * NT], mup = inv[2 * NT], mupp = inv[3 * NT];
+            const double mv1 = inv[4 * NT], mv0 = inv[5 * NT], mvp = inv[6 * NT], mvpp = inv[7 * NT];
+            double DC = 0.0;
+            if (MODE == 0) DC = 1.0 / (hz - pmn * (Hu1 - Hu0 + Hv1 - Hv0 + (Wk1 - Wk)));
+#pragma unroll
+            for (int n = 0; n < RH_NCONS; n++) {
+                const double t0 = w0[n];
+                const double *c0 = st[n] + (ty + 2) * TT::PX + (tx + 2);
+                const double tm2 = c0[-2], tm1 = c0[-1], tp1 = c0[1], tp2 = c0[2];
+                const double sm2 = c0[-2 * TT::PX], sm1 = c0[-TT::PX], sp1 = c0[TT::PX], sp2 = c0[2 * TT::PX];
+                double FX0, FX1, FE0, FE1;
+                if (SCHEME == 2) {
+                    FX0 = Hu0 * 0.5 * (tm1 + t0); FX1 = Hu1 * 0.5 * (t0 + tp1);
+                    FE0 = Hv0 * 0.5 * (sm1 + t0); FE1 = Hv1 * 0.5 * (t0 + sp1);
+                } else if (SCHEME == 0) {
+                    FX0 = a3_tflux_u3(tm2, tm1, t0, tp1, mu1, mu0, mup, Hu0, sgn); FX1 = a3_tflux_u3(tm1, t0, tp1, tp2, mu0, mup, mupp, Hu1, sgn);
+                    FE0 = a3_tflux_u3(sm2, sm1, t0, sp1, mv1, mv0, mvp, Hv0, sgn); FE1 = a3_tflux_u3(sm1, t0, sp1, sp2, mv0, mvp, mvpp, Hv1, sgn);
+                } else {
+                    FX0 = a3_tflux_c4(tm2, tm1, t0, tp1, mu1, mu0, mup, Hu0, c4mode); FX1 = a3_tflux_c4(tm1, t0, tp1, tp2, mu0, mup, mupp, Hu1, c4mode);
+                    FE0 = a3_tflux_c4(sm2, sm1, t0, sp1, mv1, mv0, mvp, Hv0, c4mode); FE1 = a3_tflux_c4(sm1, t0, sp1, sp2, mv0, mvp, mvpp, Hv1, c4mode);
+                }
+                const double FCk1 = win_flux_w(wm1[n], w0[n], wp1[n], wp2[n], k + 1, N, Wk1);
+                if (MODE == 0) {
+                    const double store = hz * (P.cff1 * t0 + P.cff2 * cn[n]) - pmn * (FX1 - FX0 + FE1 - FE0);
+                    const double c4 = FCk1 - FCk[n];
+                    sst(i, j, k, n) = DC * (store - pmn * c4);
+                    double tn = t0 * 0.5 * (hz + hz);
+                    if (P.mix_on[n]) {
+                        const double *h0 = sh + (ty + 1) * TH::PX + (tx + 1);
+                        const double hzxm = h0[-1], hzxp = h0[1], hzym = h0[-TH::PX], hzyp = h0[TH::PX];
+                        double GX0 = inv[(8 + 4 * n) * NT] * (hz + hzxm) * (t0 - tm1); GX0 *= mu0;
+                        double GX1 = inv[(9 + 4 * n) * NT] * (hzxp + hz) * (tp1 - t0); GX1 *= mup;
+                        double GE0 = inv[(10 + 4 * n) * NT] * (hz + hzym) * (t0 - sm1); GE0 *= mv0;
+                        double GE1 = inv[(11 + 4 * n) * NT] * (hzyp + hz) * (sp1 - t0); GE1 *= mvp;
+                        tn += cmix * ((GX1 - GX0) + (GE1 - GE0));
+                    }
+                    cnew(i, j, k, n) = tn;
+                } else {
+                    double x = cn[n];
+                    const double cff1 = pmn * (FX1 - FX0);
+                    const double cff2 = pmn * (FE1 - FE0);
+                    const double cff3 = cff1 + cff2;
+                    x -= cff3;
+                    const double cff4 = FCk1 - FCk[n];
+                    cnew(i, j, k, n) = (x - pmn * cff4) / hz;
+                }
+                FCk[n] = FCk1;
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < RH_NCONS; n++) { wm1[n] = w0[n]; w0[n] = wp1[n]; wp1[n] = wp2[n]; wp2[n] = nx2[n]; cn[n] = cn_n[n]; tha[n] = tha_n[n]; }
+        Hu0 = Hu0_n; Hv0 = Hv0_n; hz = hz_n; uha = uha_n; vha = vha_n; hha = hha_n; Wk = Wk1; Wk1 = Wk2;
+    }
+}
+
+static int tracers_tiled(rh_ctx *c, rh_state *s, int mode, int iic, int ntfirst)
+{
+    const int N = c->N; const double dt = c->prm.dt;
+    rh_box bx = c->bx; bx.lo[2] = 0; bx.hi[2] = N;
+    const rh_box g2 = bx_grow(bx, 2, 2, 0), g1 = bx_grow(bx, 1, 1, 0), b2 = bx_slab(bx, 2, 0);
+    rh_box bw = bx; bw.hi[2] = N + 1;
+    const rh_array4 &adv = mode == 0 ? s->cons_old : s->sstore;
+    if (s->cons_old.ncomp < RH_NCONS || s->cons_new.ncomp < RH_NCONS || s->sstore.ncomp < RH_NCONS || s->diff2.ncomp < RH_NCONS)
+        return rh_fail("tracers_tiled: tracer arrays need %d components", RH_NCONS);
+    RH_NEED(adv, g2); RH_NEED(s->cons_new, bx); RH_NEED(s->sstore, bx); RH_NEED(s->Hz, mode == 0 ? g1 : bx); RH_NEED(c->W, bw);
+    RH_NEED(s->Huon, bx_nodal(bx, 0)); RH_NEED(s->Hvom, bx_nodal(bx, 1)); RH_NEED(s->pm, bx_slab(g1, 2, 0)); RH_NEED(s->pn, bx_slab(g1, 2, 0));
+    { rh_box m = b2; m.lo[0] -= 1; m.hi[0] += 2; RH_NEED(s->msku, m); }
+    { rh_box m = b2; m.lo[1] -= 1; m.hi[1] += 2; RH_NEED(s->mskv, m); }
+    if (mode == 0) { rh_box d = bx_slab(g1, 2, 0); d.hi[2] = 1; RH_NEED(s->diff2, d); }
+    TrcPar P; memset(&P, 0, sizeof P);
+    P.N = N; P.flat = c->prm.flat_bathymetry ? 1 : 0; P.dt = dt;
+    if (mode == 0) {
+        const double GammaT = 1.0 / 6.0;
+        if (iic == ntfirst) { P.cff = 0.5 * dt; P.cff1 = 1.0; P.cff2 = 0.0; }
+        else { P.cff = (1.0 - GammaT) * dt; P.cff1 = 0.5 + GammaT; P.cff2 = 0.5 - GammaT; }
+        // which (component, level) of diff2 each tracer's t3dmix reads: setup_step.cpp:283-286 + the 3-index access of t3dmix.cpp:34,43
+        P.mix_on[0] = 1; P.mix_comp[0] = 0; P.mix_k[0] = 0;
+        P.mix_on[1] = c->prm.use_salt ? 1 : 0; P.mix_comp[1] = 0; P.mix_k[1] = 1;
+        P.mix_on[2] = 1; P.mix_comp[2] = 2; P.mix_k[2] = 0;
+    }
+    const int scheme = (mode == 0 && c->prm.flat_bathymetry) ? 2 : (c->prm.tracer_c4 ? 1 : 0);
+#define RH_TT(M, S) k_tracers_tiled<M, S><<<rt_grid(bx), rt_block(), 0, c->stream>>>(mkB(bx), mkA(adv), mkA(s->cons_new), mkA(s->sstore), mkA(s->Hz), \
+        mkA(s->Huon), mkA(s->Hvom), mkA(c->W), mkA(s->pm), mkA(s->pn), mkA(s->msku), mkA(s->mskv), mkA(s->diff2), P)
+    if (mode == 0) { if (scheme == 0) RH_TT(0, 0); else if (scheme == 1) RH_TT(0, 1); else RH_TT(0, 2); }
+    else { if (scheme == 0) RH_TT(1, 0); else RH_TT(1, 1); }
+#undef RH_TT
+    RH_LAUNCH_CHECK(); return 0;
+}
+int launch_prestep_t3(rh_ctx *c, rh_state *s, int iic, int ntfirst) { TScope t(c, "prestep_t3"); return tracers_tiled(c, s, 0, iic, ntfirst); }
+int launch_rhs_t3(rh_ctx *c, rh_state *s) { TScope t(c, "rhs_t3"); return tracers_tiled(c, s, 1, 0, 0); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // cons *= mskr, REMORA_advance_3d_ml.cpp:51-62

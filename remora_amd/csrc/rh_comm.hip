@@ -86,3 +86,33 @@ int comm_exchange(rh_ctx *c, long n_lo, int peer_lo, long n_hi, int peer_hi)
 #undef RH_NCCL
     return 0;
 }
+
+// Diagnostic: push two n-double patterns through the active transport to THIS rank (peer_lo = peer_hi = self) and check
+// that the block sent "down" arrives "from above" and vice versa -- the message order a two-rank periodic run relies on.
+__global__ void k_pattern(double *p, long n, double base) { long q = (long)blockIdx.x * blockDim.x + threadIdx.x; if (q < n) p[q] = base + (double)q; }
+extern "C" int rh_comm_selftest(rh_ctx *c, long n)
+{
+    if (!c || n <= 0) return rh_fail("rh_comm_selftest: bad argument");
+    if (!c->xfn && !c->comm) return rh_fail("rh_comm_selftest: no communicator");
+    if (n > c->xcap) {
+        RH_HIP(hipStreamSynchronize(c->stream));
+        if (c->d_xbuf) RH_HIP(hipFree(c->d_xbuf));
+        c->xcap = (n + 4095) / 4096 * 4096; c->d_xbuf = nullptr;
+        RH_HIP(hipMalloc((void **)&c->d_xbuf, sizeof(double) * 4 * c->xcap));
+    }
+    RH_HIP(hipMemsetAsync(c->d_xbuf, 0, sizeof(double) * 4 * c->xcap, c->stream));
+    const int nb = (int)((n + 255) / 256);
+    k_pattern<<<nb, 256, 0, c->stream>>>(c->d_xbuf, n, 1.0e6);                 // send_lo
+    k_pattern<<<nb, 256, 0, c->stream>>>(c->d_xbuf + c->xcap, n, 2.0e6);       // send_hi
+    RH_LAUNCH_CHECK();
+    RH_TRY(comm_exchange(c, n, c->rank, n, c->rank));
+    std::vector<double> lo(n), hi(n);
+    RH_HIP(hipMemcpyAsync(lo.data(), c->d_xbuf + 2 * c->xcap, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipMemcpyAsync(hi.data(), c->d_xbuf + 3 * c->xcap, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    for (long q = 0; q < n; q++) {
+        if (hi[q] != 1.0e6 + (double)q) return rh_fail("rh_comm_selftest: recv_hi[%ld] = %g, expected the block sent down (%g)", q, hi[q], 1.0e6 + (double)q);
+        if (lo[q] != 2.0e6 + (double)q) return rh_fail("rh_comm_selftest: recv_lo[%ld] = %g, expected the block sent up (%g)", q, lo[q], 2.0e6 + (double)q);
+    }
+    return 0;
+}

@@ -10,21 +10,24 @@
 #include "../../include/remora_hip.h"
 
 // Device-side view with the amrex::Array4 memory order (i fastest).  Built once per launch on the host.
+// Indexing is 32-bit unsigned: the offset then rides in one VGPR next to a scalar base pointer (global_load ... v, s[base]),
+// which halves the address arithmetic of these load-heavy stencils.  Every array that reaches a kernel passes RH_NEED first,
+// which rejects arrays of 2^32 elements or more (34 GB; a state of ~35 such components would not fit the 288 GB of one GPU).
 struct A4 {
-    double *p; int lo0, lo1, lo2, hi0, hi1, hi2, nc; long sy, sz, sn;
-    __host__ __device__ __forceinline__ long ix(int i, int j, int k) const
-    { return (long)(i - lo0) + (long)(j - lo1) * sy + (long)(k - lo2) * sz; }
+    double *p; int lo0, lo1, lo2, hi0, hi1, hi2, nc; unsigned sy, sz, sn;
+    __host__ __device__ __forceinline__ unsigned ix(int i, int j, int k) const
+    { return (unsigned)(i - lo0) + (unsigned)(j - lo1) * sy + (unsigned)(k - lo2) * sz; }
     __device__ __forceinline__ double &operator()(int i, int j, int k) const { return p[ix(i, j, k)]; }
-    __device__ __forceinline__ double &operator()(int i, int j, int k, int n) const { return p[ix(i, j, k) + (long)n * sn]; }
+    __device__ __forceinline__ double &operator()(int i, int j, int k, int n) const { return p[ix(i, j, k) + (unsigned)n * sn]; }
 };
 
 static inline A4 mkA(const rh_array4 &a)
 {
     A4 r; r.p = a.p; r.lo0 = a.lo[0]; r.lo1 = a.lo[1]; r.lo2 = a.lo[2]; r.hi0 = a.hi[0]; r.hi1 = a.hi[1]; r.hi2 = a.hi[2];
-    r.nc = a.ncomp; r.sy = a.hi[0] - a.lo[0] + 1; r.sz = r.sy * (a.hi[1] - a.lo[1] + 1); r.sn = r.sz * (a.hi[2] - a.lo[2] + 1);
+    r.nc = a.ncomp; r.sy = (unsigned)(a.hi[0] - a.lo[0] + 1); r.sz = r.sy * (unsigned)(a.hi[1] - a.lo[1] + 1); r.sn = r.sz * (unsigned)(a.hi[2] - a.lo[2] + 1);
     return r;
 }
-static inline A4 mkA(const rh_array4 &a, int comp) { A4 r = mkA(a); r.p += r.sn * comp; r.nc -= comp; return r; }
+static inline A4 mkA(const rh_array4 &a, int comp) { A4 r = mkA(a); r.p += (long)r.sn * comp; r.nc -= comp; return r; }
 static inline long a4_size(const rh_array4 &a)
 { return (long)(a.hi[0]-a.lo[0]+1)*(a.hi[1]-a.lo[1]+1)*(a.hi[2]-a.lo[2]+1)*a.ncomp; }
 static inline rh_array4 a4_comp(rh_array4 a, int comp)
@@ -72,7 +75,8 @@ int rh_fail(const char *fmt, ...);
 #define RH_TRY(x) do { int r_ = (x); if (r_) return r_; } while (0)
 #define RH_LAUNCH_CHECK() RH_HIP(hipGetLastError())
 // operand-shape guard used before every launch: the box a kernel indexes must lie inside the array it indexes
-#define RH_NEED(arr, box) do { if (!bx_contains(bx_of(arr), (box))) return rh_fail("%s: array %s [%d:%d,%d:%d,%d:%d] does not cover box [%d:%d,%d:%d,%d:%d] (%s:%d)", __func__, #arr, \
+#define RH_NEED(arr, box) do { if (a4_size(arr) >= (1L << 32)) return rh_fail("%s: array %s has %ld elements; 32-bit indexing needs < 2^32 (decompose further)", __func__, #arr, a4_size(arr)); \
+    if (!bx_contains(bx_of(arr), (box))) return rh_fail("%s: array %s [%d:%d,%d:%d,%d:%d] does not cover box [%d:%d,%d:%d,%d:%d] (%s:%d)", __func__, #arr, \
     (arr).lo[0],(arr).hi[0],(arr).lo[1],(arr).hi[1],(arr).lo[2],(arr).hi[2],(box).lo[0],(box).hi[0],(box).lo[1],(box).hi[1],(box).lo[2],(box).hi[2], __FILE__, __LINE__); } while (0)
 
 struct BCRec3 { int lo[3], hi[3]; };
@@ -101,6 +105,7 @@ struct rh_ctx {
     std::vector<std::string> tnames; std::map<std::string,int> tslot;
     std::vector<std::vector<std::pair<hipEvent_t,hipEvent_t>>> tev;
     std::vector<hipEvent_t> evpool;
+    bool unfused = false;            // RH_UNFUSED=1: drivers call the per-leaf entry points instead of the fused kernels (A/B parity)
     bool poison = false;             // RH_POISON=1: NaN-fill the work space at the start of every step (stale-read detector)
 };
 
@@ -124,6 +129,8 @@ int  launch_vmix(rh_ctx *c, rh_state *s);
 int  launch_set_zeta(rh_ctx *c, rh_state *s);
 int  launch_uv_ab3(rh_ctx *c, rh_state *s, int istep);
 int  launch_mask_cons(rh_ctx *c, rh_state *s);
+int  launch_prestep_t3(rh_ctx *c, rh_state *s, int iic, int ntfirst);   // fused: 3 tracers x (prestep_t + t3dmix)
+int  launch_rhs_t3(rh_ctx *c, rh_state *s);                             // fused: 3 tracers x rhs_t_3d
 void comm_release(rh_ctx *c);                                   // rh_comm.hip
 int  comm_exchange(rh_ctx *c, long n_lo, int peer_lo, long n_hi, int peer_hi);   // d_xbuf slots, on c->stream
 // small utilities (rh_ctx.hip)

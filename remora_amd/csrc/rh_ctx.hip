@@ -291,6 +291,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     for (int d = 0; d < 2; d++) if (prm->periodic[d] && (c->dom.hi[d] - c->dom.lo[d] + 1) < 4) return bad("periodic direction shorter than the ghost width");
     c->nfast = set_weights(prm->ndtfast, c->w1, c->w2);
     init_bcs(c);
+    c->unfused = getenv("RH_UNFUSED") && atoi(getenv("RH_UNFUSED")) != 0;
     c->poison = getenv("RH_POISON") && atoi(getenv("RH_POISON")) != 0;
 
     // stretching curves (here N = nz, DepthStretchTransform.H:49)

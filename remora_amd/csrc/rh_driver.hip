@@ -67,11 +67,15 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     RH_TRY(set_analytical_vmix(c, s));                                                             // :203-206
     RH_TRY(launch_set_zeta(c, s));                                                                 // :208
     RH_TRY(dev_setval(c, c->W, 0, 1, 0.0));                                                        // :210-211
+    bool fused_t = false;
     if (P.use_prestep) {                                                                           // :216, REMORA_prestep.cpp
         RH_TRY(rh_omega(c, bx_grow(bx, 1, 1, 0), c->W, s->Huon, s->Hvom, s->z_w, s->h, N));        // prestep_t_advection.cpp:97-125 (identical for all tracers)
-        for (int n = 0; n < RH_NCONS; n++)
-            RH_TRY(rh_prestep_t(c, bx, a4_comp(s->cons_old, n), a4_comp(s->cons_new, n), a4_comp(s->sstore, n), s->Hz, s->Huon, s->Hvom, c->W,
-                                s->pm, s->pn, s->msku, s->mskv, iic, ntfirst, N, dt));
+        fused_t = !c->unfused;
+        if (fused_t) RH_TRY(launch_prestep_t3(c, s, iic, ntfirst));             // 3 tracers x (prestep_t + t3dmix of :283-286) in one sweep
+        else
+            for (int n = 0; n < RH_NCONS; n++)
+                RH_TRY(rh_prestep_t(c, bx, a4_comp(s->cons_old, n), a4_comp(s->cons_new, n), a4_comp(s->sstore, n), s->Hz, s->Huon, s->Hvom, c->W,
+                                    s->pm, s->pn, s->msku, s->mskv, iic, ntfirst, N, dt));
         const rh_box tbxp1 = bx_grow(bx, 1, 1, 0);
         RH_TRY(rh_prestep_uv(c, tbxp1, 1, 0, s->xvel_new, s->xvel_old, s->ru, s->Hz, s->sustr, s->bustr, s->pm, s->pn, iic, ntfirst, nrhs, N, dt));
         RH_TRY(rh_prestep_uv(c, tbxp1, 0, 1, s->yvel_new, s->yvel_old, s->rv, s->Hz, s->svstr, s->bvstr, s->pm, s->pn, iic, ntfirst, nrhs, N, dt));
@@ -84,8 +88,10 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     }
     const rh_box xbx = bx_nodal(bx, 0), ybx = bx_nodal(bx, 1);
     RH_TRY(rh_prsgrd(c, bx_grow(bx, 1, 1, 0), xbx, ybx, s->ru, s->rv, s->pn, s->pm, c->rho, c->P, s->Hz, s->z_r, s->z_w, s->msku, s->mskv, nrhs, N));
-    RH_TRY(rh_t3dmix(c, bx, s->cons_new, s->cons_old, s->diff2, s->Hz, s->pm, s->pn, s->msku, s->mskv, dt, P.use_salt ? 2 : 1));   // :283-286
-    RH_TRY(rh_t3dmix(c, bx, a4_comp(s->cons_new, 2), a4_comp(s->cons_old, 2), a4_comp(s->diff2, 2), s->Hz, s->pm, s->pn, s->msku, s->mskv, dt, 1));
+    if (!fused_t) {
+        RH_TRY(rh_t3dmix(c, bx, s->cons_new, s->cons_old, s->diff2, s->Hz, s->pm, s->pn, s->msku, s->mskv, dt, P.use_salt ? 2 : 1));   // :283-286
+        RH_TRY(rh_t3dmix(c, bx, a4_comp(s->cons_new, 2), a4_comp(s->cons_old, 2), a4_comp(s->diff2, 2), s->Hz, s->pm, s->pn, s->msku, s->mskv, dt, 1));
+    }
     RH_TRY(rh_rhs_uv_3d(c, xbx, ybx, s->xvel_old, s->yvel_old, s->ru, s->rv, s->rufrc, s->rvfrc, s->sustr, s->svstr, s->bustr, s->bvstr,
                         s->Huon, s->Hvom, s->pm, s->pn, c->W, s->Hz, s->fcor, P.use_coriolis, nrhs, N));
     if (P.use_uv3dmix)
@@ -122,7 +128,8 @@ static int advance_3d(rh_ctx *c, rh_state *s, int istep)
     RH_TRY(rh_update_massflux_3d(c, gbx2, 0, 1, s->yvel_new, s->vbar, s->Hvom, s->Hz, s->pm, s->DV_avg1, s->DV_avg2, s->mskv, N));   // :218
     RH_TRY(dev_setval(c, c->W, 0, 1, 0.0));                                                        // :230-231
     RH_TRY(rh_omega(c, gbx1, c->W, s->Huon, s->Hvom, s->z_w, s->h, N));                            // :272-293
-    for (int n = 0; n < RH_NCONS; n++)                                                             // :341-346
+    if (!c->unfused) RH_TRY(launch_rhs_t3(c, s));                                                  // :341-346, 3 tracers in one sweep
+    else for (int n = 0; n < RH_NCONS; n++)
         RH_TRY(rh_rhs_t_3d(c, bx, a4_comp(s->cons_new, n), a4_comp(s->sstore, n), s->Huon, s->Hvom, s->Hz, s->pn, s->pm, c->W, s->msku, s->mskv, N, dt));
     { TScope t(c, "halo"); RH_TRY(halo_fillpatch(c, mfv(c, s->cons_new, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS)); }   // :350
     for (int n = 0; n < RH_NCONS; n++)                                                             // :382-385

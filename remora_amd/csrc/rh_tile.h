@@ -1,0 +1,69 @@
+// rh_tile.h -- LDS-staged 2-D tiles with halo for the horizontal stencils.
+//
+// Measured on MI355X (profiles/): a neighbour re-load (i+-1, i+-2, j+-1, ...) issued while the line is still in flight is not
+// merged by L1/L2, so a kernel that reads its stencil straight from global memory moves ~(load instructions x 8 B) over the
+// fabric: 2-7x the algorithmic bytes.  Here every block stages one (64+2HX) x (BY+2HY) tile per field and level in LDS: each
+// thread contributes the value of its own point (which it loads exactly once), the first threads of the block fetch the
+// halo ring, and all stencil neighbours are then read from LDS.  Tiles are double-buffered on the parity of k so that a
+// k-marching kernel needs ONE __syncthreads() per level.
+#pragma once
+#include "rh_common.h"
+
+#define RT_BX 64          // threads along i: one wavefront, 512-B rows
+#define RT_BY 8           // rows of j per block (8 wavefronts)
+static inline dim3 rt_block() { return dim3(RT_BX, RT_BY, 1); }
+static inline dim3 rt_grid(const rh_box &b) { return dim3((b.hi[0] - b.lo[0] + RT_BX) / RT_BX, (b.hi[1] - b.lo[1] + RT_BY) / RT_BY, 1); }
+
+template <int HX, int HY>
+struct Tile {
+    static constexpr int PX = RT_BX + 2 * HX, PY = RT_BY + 2 * HY, SIZE = PX * PY;
+    static constexpr int NROWCELLS = 2 * HY * PX, NHALO = NROWCELLS + 2 * HX * RT_BY;
+    double *s;
+    // value at tile-relative offset (di,dj) from this thread's own point
+    __device__ __forceinline__ double at(int tx, int ty, int di, int dj) const { return s[(ty + HY + dj) * PX + (tx + HX + di)]; }
+    // stage level k of `a`: own point value `c` (already loaded by the caller), halo ring fetched here.  (i0,j0) = global index
+    // of thread (0,0)'s point.  Cells outside the array are left untouched (no consumer inside the kernel's box reads them).
+    __device__ __forceinline__ void fill(const A4 &a, int k, int i0, int j0, int tx, int ty, double c) const
+    {
+        s[(ty + HY) * PX + (tx + HX)] = c;
+        if (NHALO > 0) {
+            for (int t = ty * RT_BX + tx; t < NHALO; t += RT_BX * RT_BY) {
+                int x, y;
+                if (t < NROWCELLS) { const int r = t / PX; x = t - r * PX; y = r < HY ? r : RT_BY + r; }
+                else { const int u = t - NROWCELLS; constexpr int W2 = 2 * HX > 0 ? 2 * HX : 1; const int r = u / W2; const int xx = u - r * W2; y = HY + r; x = xx < HX ? xx : RT_BX + xx; }
+                const int gi = i0 - HX + x, gj = j0 - HY + y;
+                if (gi >= a.lo0 && gi <= a.hi0 && gj >= a.lo1 && gj <= a.hi1) s[y * PX + x] = a(gi, gj, k);
+            }
+        }
+    }
+};
+// Software-pipelined form: a thread's halo cell is fixed for the whole kernel, so it is located once (HaloCell), its value
+// for level k+1 is fetched into a register while level k is being computed, and put() writes own value + halo value into LDS
+// at the top of the next iteration -- no load sits between the LDS stores and the barrier.  One halo cell per thread at most.
+struct HaloCell { int lds; unsigned g; };    // LDS offset inside the tile (-1: none) and element offset inside one k-plane of the array
+template <int HX, int HY>
+__device__ __forceinline__ HaloCell halo_cell(const A4 &a, int i0, int j0, int tx, int ty)
+{
+    typedef Tile<HX, HY> T;
+    static_assert(T::NHALO <= RT_BX * RT_BY, "one halo cell per thread");
+    HaloCell h; h.lds = -1; h.g = 0;
+    const int t = ty * RT_BX + tx;
+    if (t < T::NHALO) {
+        int x, y;
+        if (t < T::NROWCELLS) { const int r = t / T::PX; x = t - r * T::PX; y = r < HY ? r : RT_BY + r; }
+        else { constexpr int W2 = 2 * HX > 0 ? 2 * HX : 1; const int u = t - T::NROWCELLS; const int r = u / W2; const int xx = u - r * W2; y = HY + r; x = xx < HX ? xx : RT_BX + xx; }
+        const int gi = i0 - HX + x, gj = j0 - HY + y;
+        if (gi >= a.lo0 && gi <= a.hi0 && gj >= a.lo1 && gj <= a.hi1) { h.lds = y * T::PX + x; h.g = (unsigned)(gi - a.lo0) + (unsigned)(gj - a.lo1) * a.sy; }
+    }
+    return h;
+}
+__device__ __forceinline__ double halo_ld(const A4 &a, const HaloCell &h, int k) { return h.lds >= 0 ? a.p[h.g + (unsigned)(k - a.lo2) * a.sz] : 0.0; }
+template <int HX, int HY>
+__device__ __forceinline__ void tile_put(double *s, int tx, int ty, double own, const HaloCell &h, double hv)
+{
+    s[(ty + HY) * Tile<HX, HY>::PX + (tx + HX)] = own;
+    if (h.lds >= 0) s[h.lds] = hv;
+}
+// own-point load guarded by the array box (threads of a partial block outside the array contribute nothing)
+__device__ __forceinline__ double ld_in(const A4 &a, int i, int j, int k)
+{ return (i >= a.lo0 && i <= a.hi0 && j >= a.lo1 && j <= a.hi1) ? a(i, j, k) : 0.0; }

@@ -54,6 +54,20 @@ def test_phases_against_oracle(case):
     rem.close(); orc.close()
 
 
+@pytest.mark.parametrize("case", ["Seamount", "Advection"])
+def test_leaf_entry_points_against_oracle(case, monkeypatch):
+    """RH_UNFUSED=1 makes the drivers go through the per-leaf C entry points (rh_prestep_t, rh_t3dmix, rh_rhs_t_3d, ...) instead
+    of the fused multi-tracer kernels: both routes must agree with the oracle (and hence with each other)."""
+    monkeypatch.setenv("RH_UNFUSED", "1")
+    cfg = cases.get(case)
+    orc = Oracle(cfg); rem = REMORA(cfg)
+    upload_oracle_state(orc, rem)
+    for step in range(3):
+        orc.advance(1); rem.timeStep()
+        _check(compare_states(orc, rem), case, f"unfused step {step}")
+    rem.close(); orc.close()
+
+
 @pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection"])
 def test_gold_plotfile(case):
     """Device-side initial state + ten steps through REMORA::Advance == the reference's regression test."""
@@ -93,3 +107,16 @@ def test_drift_vs_oracle(case, from_oracle_init, bound):
             worst_rel = max(worst_rel, max(rel))
     assert worst_rel < bound
     rem.close(); orc.close()
+
+
+def test_rccl_transport_selftest():
+    """The built-in RCCL transport on a one-rank communicator: unique id, ncclCommInitRank, grouped send/recv to self, and
+    the message order a two-rank periodic exchange relies on (more ranks than GPUs cannot be formed on a one-GPU box)."""
+    import ctypes as C
+    from remora_amd import lib as L
+    rem = REMORA(cases.get("Seamount"))
+    idbuf = (C.c_ubyte * 128)()
+    L.check(rem.lib.rh_comm_unique_id(idbuf))
+    L.check(rem.lib.rh_comm_init(rem.ctx, idbuf, 0, 1))
+    L.check(rem.lib.rh_comm_selftest(rem.ctx, 100000))
+    rem.close()
