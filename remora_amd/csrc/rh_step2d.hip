@@ -8,12 +8,12 @@
 // separated only where a ghost exchange (:170-171) or a neighbour dependency forces it.  One thread per (i,j).
 #include "rh_common.h"
 #include "rh_uvmix.h"
+#include "rh_tile.h"
 
-__global__ void k2d_flux(B3 b3, B3 xg, B3 yg, A4 zeta, A4 h, A4 ubar, A4 vbar, A4 pm, A4 pn, A4 Drhs, A4 DUon, A4 DVom)
+__global__ void k2d_flux(B3 b3, B3 xg, B3 yg, A4 zeta, A4 h, A4 ubar, A4 vbar, A4 pm, A4 pn, A4 DUon, A4 DVom)
 {
     RH_IJ(b3); if (!inb2(b3, i, j)) return;
-    const double d0 = zeta(i, j, 0) + h(i, j, 0);
-    Drhs(i, j, 0) = d0;
+    const double d0 = zeta(i, j, 0) + h(i, j, 0);          // Drhs, :149-152 (rebuilt by its consumers, never stored)
     if (inb2(xg, i, j)) {
         const double on_u = 2.0 / (pn(i, j, 0) + pn(i - 1, j, 0));
         const double cff1 = 0.5 * on_u * (d0 + (zeta(i - 1, j, 0) + h(i - 1, j, 0)));
@@ -37,7 +37,7 @@ struct ZetaPar {
 
 __global__ void k2d_zeta(B3 g3, B3 xg, B3 yg, B3 t1, ZetaPar zp, A4 zeta_rhs, A4 zeta_stp, A4 zeta_new_o, A4 rzeta_stp, A4 rzeta_pts,
                          A4 rzeta_rhs, A4 h, A4 pm, A4 pn, A4 mskr, A4 rhoS, A4 rhoA, A4 DUon, A4 DVom, A4 Zt_avg1,
-                         A4 DU_avg1, A4 DU_avg2, A4 DV_avg1, A4 DV_avg2, A4 Dnew, A4 zwrk_o, A4 gzeta_o, A4 gzeta2_o, A4 gzetaSA_o)
+                         A4 DU_avg1, A4 DU_avg2, A4 DV_avg1, A4 DV_avg2, A4 zwrk_o)
 {
     RH_IJ(g3); if (!inb2(g3, i, j)) return;
     // ---- time averages, :293-356
@@ -55,9 +55,8 @@ __global__ void k2d_zeta(B3 g3, B3 xg, B3 yg, B3 t1, ZetaPar zp, A4 zeta_rhs, A4
     }
     if (!zp.do_step || !inb2(t1, i, j)) return;
     // ---- free surface, :379-464
-    const double fac = 1000.0 / 1025.0;                                        // :379
     const double div = (DUon(i, j, 0) - DUon(i + 1, j, 0)) + (DVom(i, j, 0) - DVom(i, j + 1, 0));
-    const double zs = zeta_stp(i, j, 0), hh = h(i, j, 0), rS = rhoS(i, j, 0), rA = rhoA(i, j, 0);
+    const double zs = zeta_stp(i, j, 0);
     double zn, zw;
     if (zp.zmode == 0) {
         const double cff1 = zp.dtfast;
@@ -74,12 +73,7 @@ __global__ void k2d_zeta(B3 g3, B3 xg, B3 yg, B3 t1, ZetaPar zp, A4 zeta_rhs, A4
         zn *= mskr(i, j, 0);
         zw = cff5 * zn + cff4 * zeta_rhs(i, j, 0);
     }
-    Dnew(i, j, 0) = zn + hh;
-    zwrk_o(i, j, 0) = zw;
-    const double gz = (fac + rS) * zw;
-    gzeta_o(i, j, 0) = gz;
-    gzeta2_o(i, j, 0) = gz * zw;
-    gzetaSA_o(i, j, 0) = zw * (rS - rA);
+    zwrk_o(i, j, 0) = zw;        // Dnew, gzeta, gzeta2, gzetaSA (:392-394 ...) are rebuilt from zwrk / rhoS / rhoA / zeta(knew) / h in k2d_uvbar
     zeta_new_o(i, j, 0) = zn;                                                  // :450-454
     if (zp.predictor) rzeta_rhs(i, j, 0) = div;                                // :459-464
 }
@@ -93,7 +87,8 @@ struct UVPar {
 };
 
 // 2-D momentum advection fluxes, REMORA_rhs_uv_2d.cpp:80-129,171-216 (u, v = ubar/vbar(krhs))
-__device__ __forceinline__ double s2_UFx(const A4 &u, const A4 &DU, int i, int j, const UVPar &g)
+template <class TA, class TB>
+__device__ __forceinline__ double s2_UFx(const TA &u, const TB &DU, int i, int j, const UVPar &g)
 {
     if (g.uv_c2) return 0.25 * (DU(i, j, 0) + DU(i + 1, j, 0)) * (u(i, j, 0) + u(i + 1, j, 0));
     const double um = u(i - 1, j, 0), u0 = u(i, j, 0), up = u(i + 1, j, 0), upp = u(i + 2, j, 0);
@@ -106,7 +101,8 @@ __device__ __forceinline__ double s2_UFx(const A4 &u, const A4 &DU, int i, int j
     const double ubar_avg = u0 + up;
     return 0.25 * (ubar_avg - cff * (uxx_i + uxx_ip1)) * (h0 + hp - cff * (Huxx_i + Huxx_ip1));
 }
-__device__ __forceinline__ double s2_UFe(const A4 &u, const A4 &DV, int i, int j, const UVPar &g)
+template <class TA, class TB>
+__device__ __forceinline__ double s2_UFe(const TA &u, const TB &DV, int i, int j, const UVPar &g)
 {
     if (g.uv_c2) return 0.25 * (DV(i, j, 0) + DV(i - 1, j, 0)) * (u(i, j, 0) + u(i, j - 1, 0));
     const double umm = u(i, j - 2, 0), um = u(i, j - 1, 0), u0 = u(i, j, 0), up = u(i, j + 1, 0);
@@ -120,7 +116,8 @@ __device__ __forceinline__ double s2_UFe(const A4 &u, const A4 &DV, int i, int j
     const double cff2 = h0 + hm;
     return 0.25 * (cff1 - (uee_j + uee_jm1) * cff) * (cff2 - cff * (Hvxx_i + Hvxx_im1));
 }
-__device__ __forceinline__ double s2_VFx(const A4 &v, const A4 &DU, int i, int j, const UVPar &g)
+template <class TA, class TB>
+__device__ __forceinline__ double s2_VFx(const TA &v, const TB &DU, int i, int j, const UVPar &g)
 {
     if (g.uv_c2) return 0.25 * (DU(i, j, 0) + DU(i, j - 1, 0)) * (v(i, j, 0) + v(i - 1, j, 0));
     const double cff = 1.0 / 6.0;
@@ -134,7 +131,8 @@ __device__ __forceinline__ double s2_VFx(const A4 &v, const A4 &DU, int i, int j
     const double cff2 = h0 + hm;
     return 0.25 * (cff1 - (vxx_i + vxx_im1) * cff) * (cff2 - cff * (Huee_j + Huee_jm1));
 }
-__device__ __forceinline__ double s2_VFe(const A4 &v, const A4 &DV, int i, int j, const UVPar &g)
+template <class TA, class TB>
+__device__ __forceinline__ double s2_VFe(const TA &v, const TB &DV, int i, int j, const UVPar &g)
 {
     if (g.uv_c2) return 0.25 * (DV(i, j, 0) + DV(i, j + 1, 0)) * (v(i, j, 0) + v(i, j + 1, 0));
     const double vm = v(i, j - 1, 0), v0 = v(i, j, 0), vp = v(i, j + 1, 0), vpp = v(i, j + 2, 0);
@@ -148,48 +146,84 @@ __device__ __forceinline__ double s2_VFe(const A4 &v, const A4 &DV, int i, int j
     return 0.25 * (cff1 - (vee_j + vee_jp1) * cff) * (h0 + hp - cff * (Hvee_j + Hvee_jp1));
 }
 
-__global__ void k2d_uvbar(B3 xb, B3 yb, B3 un, UVPar P, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, A4 vb_stp, A4 ub_new, A4 vb_new,
-                          A4 rubar_rhs, A4 rvbar_rhs, A4 rubar_stp, A4 rvbar_stp, A4 rubar_pts, A4 rvbar_pts,
-                          A4 zeta_stp, A4 h, A4 pm, A4 pn, A4 fcor, A4 rhoA, A4 msku, A4 mskv, A4 mskp, A4 visc2_p, A4 visc2_r,
-                          A4 rufrc, A4 rvfrc, A4 ru2d, A4 rv2d, A4 Drhs, A4 DUon, A4 DVom, A4 Dnew, A4 zwrk, A4 gzeta, A4 gzeta2, A4 gzetaSA)
+// Drhs = zeta(krhs) + h, rebuilt where it is used (bitwise the value of the reference's Drhs scratch FAB, :149-152)
+struct DrhsView { A4 z, h; __device__ __forceinline__ double operator()(int i, int j, int) const { return z(i, j, 0) + h(i, j, 0); } };
+
+// Flux sharing through LDS.  Every flux of the reference's scratch FABs (UFx, UFe, VFx, VFe of rhs_uv_2d and of uv3dmix, the
+// Coriolis terms, gzeta / gzeta2 / gzetaSA) belongs to a rho point or a psi point and is needed by two velocity points.  Phase 1:
+// each thread evaluates the 18 shared quantities of ITS point once (metric terms and their divisions included) and parks them in
+// LDS; phase 2: the u and v points combine their own values with the neighbour's (i-1 / j-1 for rho, i+1 / j+1 for psi).
+// Blocks overlap by one column and one row (stride 63 x 7 for 64 x 8 threads), so no halo pass is needed: u is produced for
+// tx >= 1, ty <= 6 and v for tx <= 62, ty >= 1.  gzeta, gzeta2, gzetaSA, Dnew, Dstp, Drhs never travel through memory.
+#define U_BY 8
+#define U_SX (RT_BX - 1)
+#define U_SY (U_BY - 1)
+enum { Q_UFX, Q_VFE, Q_MUFX, Q_MVFE, Q_CORU, Q_CORV, Q_GZ, Q_GZ2, Q_GSA, Q_H, Q_ZW, Q_RA, Q_PM, Q_PN, Q_UFE, Q_VFX, Q_MUFE, Q_MVFX, Q_N };
+__global__ void __launch_bounds__(RT_BX * U_BY)
+k2d_uvbar(B3 xb, B3 yb, B3 un, B3 rb, UVPar P, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, A4 vb_stp, A4 ub_new, A4 vb_new,
+          A4 rubar_rhs, A4 rvbar_rhs, A4 rubar_stp, A4 rvbar_stp, A4 rubar_pts, A4 rvbar_pts,
+          A4 zeta_rhs, A4 zeta_stp, A4 zeta_new, A4 h, A4 pm, A4 pn, A4 fcor, A4 rhoS, A4 rhoA, A4 msku, A4 mskv, A4 mskp, A4 visc2_p, A4 visc2_r,
+          A4 rufrc, A4 rvfrc, A4 ru2d, A4 rv2d, A4 DUon, A4 DVom, A4 zwrk)
 {
-    RH_IJ(un);
+    constexpr int NT = RT_BX * U_BY;
+    __shared__ double lds[Q_N * NT];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
+    const int i = un.lo0 - 1 + (int)blockIdx.x * U_SX + tx, j = un.lo1 - 1 + (int)blockIdx.y * U_SY + ty;
+    double *q = lds + tid;                                  // q[Q * NT]: this thread's slot of quantity Q
+    const DrhsView Drhs{zeta_rhs, h};
+    const double fac = 1000.0 / 1025.0;
+    double h0 = 0, zw0 = 0, rA0 = 0, pm0 = 0, pn0 = 0, gz0 = 0, gz20 = 0, gSA0 = 0;
+    double UFx = 0, VFe = 0, mUFx = 0, mVFe = 0, corU = 0, corV = 0, UFe = 0, VFx = 0, mUFe = 0, mVFx = 0;
+    if (inb2(rb, i, j)) {                                   // rho point (i,j), cells lo-1 .. hi+1
+        h0 = h(i, j, 0); zw0 = zwrk(i, j, 0); rA0 = rhoA(i, j, 0); pm0 = pm(i, j, 0); pn0 = pn(i, j, 0);
+        const double rS0 = rhoS(i, j, 0);
+        gz0 = (fac + rS0) * zw0; gz20 = gz0 * zw0; gSA0 = zw0 * (rS0 - rA0);               // :392-394 and the like
+        UFx = s2_UFx(ub_rhs, DUon, i, j, P);                                                 // rhs_uv_2d :80-102
+        VFe = s2_VFe(vb_rhs, DVom, i, j, P);                                                 // :193-216
+        const MixR r = mix_r_metrics(pm, pn, visc2_r, i, j);                                 // uv3dmix :48-59, :103-115 with Hz := Drhs
+        const double cffr = mix_r_cff(r, Drhs, ub_rhs, vb_rhs, i, j, 0);
+        mUFx = r.on_r * r.on_r * r.visc * cffr;
+        mVFe = r.om_r * r.om_r * r.visc * cffr;
+        if (P.use_cor) {                                                                     // coriolis :19-27,30-38 with Hz := Drhs
+            const double fm = fcor(i, j, 0) * (1.0 / (pm0 * pn0));
+            const double d = Drhs(i, j, 0);
+            corU = 0.5 * d * fm * (vb_rhs(i, j, 0) + vb_rhs(i, j + 1, 0));
+            corV = 0.5 * d * fm * (ub_rhs(i, j, 0) + ub_rhs(i + 1, j, 0));
+        }
+    }
+    if (inb2(un, i, j)) {                                   // psi point (i,j), nodes lo .. hi+1
+        UFe = s2_UFe(ub_rhs, DVom, i, j, P);                                                 // :107-129
+        VFx = s2_VFx(vb_rhs, DUon, i, j, P);                                                 // :171-191
+        const MixP p = mix_p_metrics(pm, pn, visc2_p, mskp, i, j);                           // uv3dmix :61-78, :117-134
+        const double cffp = mix_p_cff(p, Drhs, ub_rhs, vb_rhs, i, j, 0);
+        mUFe = p.om_p * p.om_p * p.visc * cffp;
+        mVFx = p.on_p * p.on_p * p.visc * cffp;
+    }
+    q[Q_UFX * NT] = UFx; q[Q_VFE * NT] = VFe; q[Q_MUFX * NT] = mUFx; q[Q_MVFE * NT] = mVFe; q[Q_CORU * NT] = corU; q[Q_CORV * NT] = corV;
+    q[Q_GZ * NT] = gz0; q[Q_GZ2 * NT] = gz20; q[Q_GSA * NT] = gSA0; q[Q_H * NT] = h0; q[Q_ZW * NT] = zw0; q[Q_RA * NT] = rA0;
+    q[Q_PM * NT] = pm0; q[Q_PN * NT] = pn0; q[Q_UFE * NT] = UFe; q[Q_VFX * NT] = VFx; q[Q_MUFE * NT] = mUFe; q[Q_MVFX * NT] = mVFx;
+    __syncthreads();
     const double cffg = 0.5 * P.g, third = 1.0 / 3.0;
-    if (inb2(xb, i, j)) {
-        // pressure gradient, :479-492
-        const double on_u = 2.0 / (pn(i, j, 0) + pn(i - 1, j, 0));
-        double rhs = cffg * on_u *
-            ((h(i - 1, j, 0) + h(i, j, 0)) * (gzeta(i - 1, j, 0) - gzeta(i, j, 0)) +
-             (h(i - 1, j, 0) - h(i, j, 0)) * (gzetaSA(i - 1, j, 0) + gzetaSA(i, j, 0) +
-                 third * (rhoA(i - 1, j, 0) - rhoA(i, j, 0)) * (zwrk(i - 1, j, 0) - zwrk(i, j, 0))) +
-             (gzeta2(i - 1, j, 0) - gzeta2(i, j, 0)));
-        // advection, rhs_uv_2d :147-153
+    if (tx >= 1 && ty <= U_BY - 2 && inb2(xb, i, j)) {
+        const double *w = q - 1, *n = q + RT_BX;            // west rho point (i-1,j), north psi point (i,j+1)
+        const double hx = w[Q_H * NT], zwx = w[Q_ZW * NT], rAx = w[Q_RA * NT], pmx = w[Q_PM * NT], pnx = w[Q_PN * NT];
+        const double on_u = 2.0 / (pn0 + pnx);
+        double rhs = cffg * on_u *                                                           // :479-492
+            ((hx + h0) * (w[Q_GZ * NT] - gz0) +
+             (hx - h0) * (w[Q_GSA * NT] + gSA0 + third * (rAx - rA0) * (zwx - zw0)) +
+             (w[Q_GZ2 * NT] - gz20));
         {
-            const double cff1 = s2_UFx(ub_rhs, DUon, i, j, P) - s2_UFx(ub_rhs, DUon, i - 1, j, P);
-            const double cff2 = s2_UFe(ub_rhs, DVom, i, j + 1, P) - s2_UFe(ub_rhs, DVom, i, j, P);
+            const double cff1 = UFx - w[Q_UFX * NT];
+            const double cff2 = n[Q_UFE * NT] - UFe;
             rhs -= (cff1 + cff2);
         }
-        // Coriolis with Hz := Drhs, :530 / REMORA_coriolis.cpp:19-27
-        if (P.use_cor) {
-            const double fm0 = fcor(i, j, 0) * (1.0 / (pm(i, j, 0) * pn(i, j, 0))), fm1 = fcor(i - 1, j, 0) * (1.0 / (pm(i - 1, j, 0) * pn(i - 1, j, 0)));
-            const double UFx_i = 0.5 * Drhs(i, j, 0) * fm0 * (vb_rhs(i, j, 0) + vb_rhs(i, j + 1, 0));
-            const double UFx_im1 = 0.5 * Drhs(i - 1, j, 0) * fm1 * (vb_rhs(i - 1, j, 0) + vb_rhs(i - 1, j + 1, 0));
-            rhs += 0.5 * (UFx_i + UFx_im1);
-        }
-        // harmonic viscosity with Hz := Drhs, dt = 0, :536-538 / REMORA_uv3dmix.cpp:48-90 (the u += 0*... update is a no-op)
+        if (P.use_cor) rhs += 0.5 * (corU + w[Q_CORU * NT]);
         {
-            const MixR r0 = mix_r_metrics(pm, pn, visc2_r, i, j), r1 = mix_r_metrics(pm, pn, visc2_r, i - 1, j);
-            const MixP p0 = mix_p_metrics(pm, pn, visc2_p, mskp, i, j), p1 = mix_p_metrics(pm, pn, visc2_p, mskp, i, j + 1);
-            const double UFx0 = r0.on_r * r0.on_r * r0.visc * mix_r_cff(r0, Drhs, ub_rhs, vb_rhs, i, j, 0);
-            const double UFx1 = r1.on_r * r1.on_r * r1.visc * mix_r_cff(r1, Drhs, ub_rhs, vb_rhs, i - 1, j, 0);
-            const double UFe0 = p0.om_p * p0.om_p * p0.visc * mix_p_cff(p0, Drhs, ub_rhs, vb_rhs, i, j, 0);
-            const double UFe1 = p1.om_p * p1.om_p * p1.visc * mix_p_cff(p1, Drhs, ub_rhs, vb_rhs, i, j + 1, 0);
-            const double cff1 = 0.5 * (pn(i - 1, j, 0) + pn(i, j, 0)) * (UFx0 - UFx1);
-            const double cff2 = 0.5 * (pm(i - 1, j, 0) + pm(i, j, 0)) * (UFe1 - UFe0);
+            const double cff1 = 0.5 * (pnx + pn0) * (mUFx - w[Q_MUFX * NT]);
+            const double cff2 = 0.5 * (pmx + pm0) * (n[Q_MUFE * NT] - mUFe);
             rhs += cff1 + cff2;
         }
-        // coupling with the 3-D forcing, :543-624
-        if (P.couple == 0) rhs += rufrc(i, j, 0);
+        if (P.couple == 0) rhs += rufrc(i, j, 0);                                            // :543-624
         else {
             double f = rufrc(i, j, 0);
             if (P.couple == 1) { f -= rhs; rhs += f; ru2d(i, j, 0, 0) = f; }
@@ -207,42 +241,31 @@ __global__ void k2d_uvbar(B3 xb, B3 yb, B3 un, UVPar P, A4 ub_rhs, A4 vb_rhs, A4
             }
             rufrc(i, j, 0) = f;
         }
-        // time step, :626-713
-        const double Dstp0 = zeta_stp(i, j, 0) + h(i, j, 0), Dstp1 = zeta_stp(i - 1, j, 0) + h(i - 1, j, 0);
-        const double cff = (pm(i, j, 0) + pm(i - 1, j, 0)) * (pn(i, j, 0) + pn(i - 1, j, 0));
-        const double Dnew_avg = 1.0 / (Dnew(i, j, 0) + Dnew(i - 1, j, 0));
+        const double Dstp0 = zeta_stp(i, j, 0) + h0, Dstp1 = zeta_stp(i - 1, j, 0) + hx;     // :626-713
+        const double cff = (pm0 + pmx) * (pn0 + pnx);
+        const double Dnew_avg = 1.0 / ((zeta_new(i, j, 0) + h0) + (zeta_new(i - 1, j, 0) + hx));
         if (!P.am3) ub_new(i, j, 0) = (ub_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * msku(i, j, 0);
         else ub_new(i, j, 0) = (ub_stp(i, j, 0) * (Dstp0 + Dstp1) +
                                 cff * (P.c1 * rhs + P.c2 * rubar_stp(i, j, 0) - P.c3 * rubar_pts(i, j, 0))) * Dnew_avg * msku(i, j, 0);
-        if (P.predictor) rubar_rhs(i, j, 0) = rhs;                             // :721-730
+        if (P.predictor) rubar_rhs(i, j, 0) = rhs;                                           // :721-730
     }
-    if (inb2(yb, i, j)) {
-        const double om_v = 2.0 / (pm(i, j, 0) + pm(i, j - 1, 0));
+    if (tx <= RT_BX - 2 && ty >= 1 && inb2(yb, i, j)) {
+        const double *sp = q - RT_BX, *e = q + 1;           // south rho point (i,j-1), east psi point (i+1,j)
+        const double hy = sp[Q_H * NT], zwy = sp[Q_ZW * NT], rAy = sp[Q_RA * NT], pmy = sp[Q_PM * NT], pny = sp[Q_PN * NT];
+        const double om_v = 2.0 / (pm0 + pmy);
         double rhs = cffg * om_v *
-            ((h(i, j - 1, 0) + h(i, j, 0)) * (gzeta(i, j - 1, 0) - gzeta(i, j, 0)) +
-             (h(i, j - 1, 0) - h(i, j, 0)) * (gzetaSA(i, j - 1, 0) + gzetaSA(i, j, 0) +
-                 third * (rhoA(i, j - 1, 0) - rhoA(i, j, 0)) * (zwrk(i, j - 1, 0) - zwrk(i, j, 0))) +
-             (gzeta2(i, j - 1, 0) - gzeta2(i, j, 0)));
+            ((hy + h0) * (sp[Q_GZ * NT] - gz0) +
+             (hy - h0) * (sp[Q_GSA * NT] + gSA0 + third * (rAy - rA0) * (zwy - zw0)) +
+             (sp[Q_GZ2 * NT] - gz20));
         {
-            const double cff1 = s2_VFx(vb_rhs, DUon, i + 1, j, P) - s2_VFx(vb_rhs, DUon, i, j, P);
-            const double cff2 = s2_VFe(vb_rhs, DVom, i, j, P) - s2_VFe(vb_rhs, DVom, i, j - 1, P);
+            const double cff1 = e[Q_VFX * NT] - VFx;
+            const double cff2 = VFe - sp[Q_VFE * NT];
             rhs -= (cff1 + cff2);
         }
-        if (P.use_cor) {
-            const double fm0 = fcor(i, j, 0) * (1.0 / (pm(i, j, 0) * pn(i, j, 0))), fm1 = fcor(i, j - 1, 0) * (1.0 / (pm(i, j - 1, 0) * pn(i, j - 1, 0)));
-            const double VFe_j = 0.5 * Drhs(i, j, 0) * fm0 * (ub_rhs(i, j, 0) + ub_rhs(i + 1, j, 0));
-            const double VFe_jm1 = 0.5 * Drhs(i, j - 1, 0) * fm1 * (ub_rhs(i, j - 1, 0) + ub_rhs(i + 1, j - 1, 0));
-            rhs -= 0.5 * (VFe_j + VFe_jm1);
-        }
+        if (P.use_cor) rhs -= 0.5 * (corV + sp[Q_CORV * NT]);
         {
-            const MixR r0 = mix_r_metrics(pm, pn, visc2_r, i, j), r1 = mix_r_metrics(pm, pn, visc2_r, i, j - 1);
-            const MixP p0 = mix_p_metrics(pm, pn, visc2_p, mskp, i, j), p1 = mix_p_metrics(pm, pn, visc2_p, mskp, i + 1, j);
-            const double VFe0 = r0.om_r * r0.om_r * r0.visc * mix_r_cff(r0, Drhs, ub_rhs, vb_rhs, i, j, 0);
-            const double VFe1 = r1.om_r * r1.om_r * r1.visc * mix_r_cff(r1, Drhs, ub_rhs, vb_rhs, i, j - 1, 0);
-            const double VFx0 = p0.on_p * p0.on_p * p0.visc * mix_p_cff(p0, Drhs, ub_rhs, vb_rhs, i, j, 0);
-            const double VFx1 = p1.on_p * p1.on_p * p1.visc * mix_p_cff(p1, Drhs, ub_rhs, vb_rhs, i + 1, j, 0);
-            const double cff1 = 0.5 * (pn(i, j - 1, 0) + pn(i, j, 0)) * (VFx1 - VFx0);
-            const double cff2 = 0.5 * (pm(i, j - 1, 0) + pm(i, j, 0)) * (VFe0 - VFe1);
+            const double cff1 = 0.5 * (pny + pn0) * (e[Q_MVFX * NT] - mVFx);
+            const double cff2 = 0.5 * (pmy + pm0) * (mVFe - sp[Q_MVFE * NT]);
             rhs += cff1 - cff2;
         }
         if (P.couple == 0) rhs += rvfrc(i, j, 0);
@@ -263,9 +286,9 @@ __global__ void k2d_uvbar(B3 xb, B3 yb, B3 un, UVPar P, A4 ub_rhs, A4 vb_rhs, A4
             }
             rvfrc(i, j, 0) = f;
         }
-        const double Dstp0 = zeta_stp(i, j, 0) + h(i, j, 0), Dstp1 = zeta_stp(i, j - 1, 0) + h(i, j - 1, 0);
-        const double cff = (pm(i, j, 0) + pm(i, j - 1, 0)) * (pn(i, j, 0) + pn(i, j - 1, 0));
-        const double Dnew_avg = 1.0 / (Dnew(i, j, 0) + Dnew(i, j - 1, 0));
+        const double Dstp0 = zeta_stp(i, j, 0) + h0, Dstp1 = zeta_stp(i, j - 1, 0) + hy;
+        const double cff = (pm0 + pmy) * (pn0 + pny);
+        const double Dnew_avg = 1.0 / ((zeta_new(i, j, 0) + h0) + (zeta_new(i, j - 1, 0) + hy));
         if (!P.am3) vb_new(i, j, 0) = (vb_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mskv(i, j, 0);
         else vb_new(i, j, 0) = (vb_stp(i, j, 0) * (Dstp0 + Dstp1) +
                                 cff * (P.c1 * rhs + P.c2 * rvbar_stp(i, j, 0) - P.c3 * rvbar_pts(i, j, 0))) * Dnew_avg * mskv(i, j, 0);
@@ -348,11 +371,11 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
     const rh_array4 ub_rhs = a4_comp(s->ubar, krhs), vb_rhs = a4_comp(s->vbar, krhs);
 
     // ---- Drhs, DUon, DVom (:149-166) and their ghost exchange (:170-171)
-    RH_NEED(s->zeta, tbxp3); RH_NEED(s->h, tbxp3); RH_NEED(c->Drhs, tbxp3);
+    RH_NEED(s->zeta, tbxp3); RH_NEED(s->h, tbxp3);
     RH_NEED(s->ubar, xgbx2); RH_NEED(s->vbar, ygbx2); RH_NEED(c->DUon, xgbx2); RH_NEED(c->DVom, ygbx2);
     RH_NEED(s->pn, bx_growlo_i(xgbx2)); RH_NEED(s->pm, bx_growlo_j(ygbx2));
     k2d_flux<<<grid2(tbxp3), rh_block(), 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkA(zeta_rhs), mkA(s->h), mkA(ub_rhs), mkA(vb_rhs),
-        mkA(s->pm), mkA(s->pn), mkA(c->Drhs), mkA(c->DUon), mkA(c->DVom));
+        mkA(s->pm), mkA(s->pn), mkA(c->DUon), mkA(c->DVom));
     RH_LAUNCH_CHECK();
     RH_TRY(halo_fill_boundary(c, mfv(c, c->DUon, 1, 0, 0), 0, 1));
     RH_TRY(halo_fill_boundary(c, mfv(c, c->DVom, 0, 1, 0), 0, 1));
@@ -370,11 +393,11 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
     zp.zmode = (my_iif == 0) ? 0 : (predictor ? 1 : 2);
     RH_NEED(s->Zt_avg1, tbxp3); RH_NEED(s->DU_avg1, xgbx2); RH_NEED(s->DU_avg2, xgbx2); RH_NEED(s->DV_avg1, ygbx2); RH_NEED(s->DV_avg2, ygbx2);
     RH_NEED(s->rzeta, tbxp1); RH_NEED(s->pm, tbxp1); RH_NEED(s->pn, tbxp1); RH_NEED(s->mskr, tbxp1); RH_NEED(s->rhoS, tbxp1); RH_NEED(s->rhoA, tbxp1);
-    RH_NEED(c->Dnew, tbxp1); RH_NEED(c->zwrk, tbxp1); RH_NEED(c->gzeta, tbxp1); RH_NEED(c->gzeta2, tbxp1); RH_NEED(c->gzetaSA, tbxp1);
+    RH_NEED(c->zwrk, tbxp1);
     k2d_zeta<<<grid2(tbxp3), rh_block(), 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkB(tbxp1), zp, mkA(zeta_rhs), mkA(zeta_stp), mkA(zeta_new),
         mkA(a4_comp(s->rzeta, kstp)), mkA(a4_comp(s->rzeta, ptsk)), mkA(a4_comp(s->rzeta, krhs < 2 ? krhs : 0)), mkA(s->h), mkA(s->pm), mkA(s->pn),
         mkA(s->mskr), mkA(s->rhoS), mkA(s->rhoA), mkA(c->DUon), mkA(c->DVom), mkA(s->Zt_avg1), mkA(s->DU_avg1), mkA(s->DU_avg2), mkA(s->DV_avg1), mkA(s->DV_avg2),
-        mkA(c->Dnew), mkA(c->zwrk), mkA(c->gzeta), mkA(c->gzeta2), mkA(c->gzetaSA));
+        mkA(c->zwrk));
     RH_LAUNCH_CHECK();
     if (my_iif >= nfast) return 0;                                             // :362-363
 
@@ -387,20 +410,23 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
     RH_TRY(need_uv2d_stencil(xbxD, ybxD, ub_rhs, vb_rhs, c->DUon, c->DVom));
     {
         const rh_box un = bx_union(xbxD, ybxD), g1 = bx_grow(un, 1, 1, 0);
-        RH_NEED(s->pm, g1); RH_NEED(s->pn, g1); RH_NEED(s->visc2_r, g1); RH_NEED(s->visc2_p, g1); RH_NEED(s->mskp, g1); RH_NEED(c->Drhs, g1);
-        RH_NEED(s->h, tbxp1); RH_NEED(s->rhoA, tbxp1); RH_NEED(s->zeta, tbxp1);
+        RH_NEED(s->pm, bx_grow(tbxp1, 1, 1, 0)); RH_NEED(s->pn, bx_grow(tbxp1, 1, 1, 0)); RH_NEED(s->visc2_r, tbxp1); RH_NEED(s->visc2_p, un); RH_NEED(s->mskp, un);
+        RH_NEED(s->h, g1); RH_NEED(s->zeta, g1); RH_NEED(s->rhoA, tbxp1); RH_NEED(s->rhoS, tbxp1); RH_NEED(c->zwrk, tbxp1);
         if (c->prm.use_coriolis) RH_NEED(s->fcor, tbxp1);
+        // the rho-point fluxes are evaluated on tbxp1 (cells lo-1 .. hi+1): their stencils must stay inside the arrays
+        { rh_box q = tbxp1; q.lo[0] -= 1; q.hi[0] += 2; RH_NEED(s->ubar, q); RH_NEED(c->DUon, q); q = tbxp1; q.lo[1] -= 1; q.hi[1] += 2; RH_NEED(s->vbar, q); RH_NEED(c->DVom, q); }
         RH_NEED(s->msku, xbxD); RH_NEED(s->mskv, ybxD); RH_NEED(s->rufrc, xbxD); RH_NEED(s->rvfrc, ybxD); RH_NEED(s->ru2d, xbxD); RH_NEED(s->rv2d, ybxD);
         RH_NEED(s->rubar, xbxD); RH_NEED(s->rvbar, ybxD); RH_NEED(s->ubar, xbxD); RH_NEED(s->vbar, ybxD);
         // rubar/rvbar(krhs) only exist for the predictor (krhs < 2); the corrector never writes them
         const int kr = krhs < 2 ? krhs : 0;
-        k2d_uvbar<<<grid2(un), rh_block(), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), P, mkA(ub_rhs), mkA(vb_rhs),
+        const dim3 grid((un.hi[0] - un.lo[0] + U_SX) / U_SX, (un.hi[1] - un.lo[1] + U_SY) / U_SY, 1);
+        k2d_uvbar<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), mkB(tbxp1), P, mkA(ub_rhs), mkA(vb_rhs),
             mkA(a4_comp(s->ubar, kstp)), mkA(a4_comp(s->vbar, kstp)), mkA(a4_comp(s->ubar, knew)), mkA(a4_comp(s->vbar, knew)),
             mkA(a4_comp(s->rubar, kr)), mkA(a4_comp(s->rvbar, kr)), mkA(a4_comp(s->rubar, kstp)), mkA(a4_comp(s->rvbar, kstp)),
             mkA(a4_comp(s->rubar, ptsk)), mkA(a4_comp(s->rvbar, ptsk)),
-            mkA(zeta_stp), mkA(s->h), mkA(s->pm), mkA(s->pn), mkA(s->fcor), mkA(s->rhoA), mkA(s->msku), mkA(s->mskv), mkA(s->mskp),
-            mkA(s->visc2_p), mkA(s->visc2_r), mkA(s->rufrc), mkA(s->rvfrc), mkA(s->ru2d), mkA(s->rv2d),
-            mkA(c->Drhs), mkA(c->DUon), mkA(c->DVom), mkA(c->Dnew), mkA(c->zwrk), mkA(c->gzeta), mkA(c->gzeta2), mkA(c->gzetaSA));
+            mkA(zeta_rhs), mkA(zeta_stp), mkA(zeta_new), mkA(s->h), mkA(s->pm), mkA(s->pn), mkA(s->fcor), mkA(s->rhoS), mkA(s->rhoA),
+            mkA(s->msku), mkA(s->mskv), mkA(s->mskp), mkA(s->visc2_p), mkA(s->visc2_r), mkA(s->rufrc), mkA(s->rvfrc), mkA(s->ru2d), mkA(s->rv2d),
+            mkA(c->DUon), mkA(c->DVom), mkA(c->zwrk));
         RH_LAUNCH_CHECK();
     }
     // ---- ghost cells of the new time level, :735-755

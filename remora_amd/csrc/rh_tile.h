@@ -14,10 +14,10 @@
 static inline dim3 rt_block() { return dim3(RT_BX, RT_BY, 1); }
 static inline dim3 rt_grid(const rh_box &b) { return dim3((b.hi[0] - b.lo[0] + RT_BX) / RT_BX, (b.hi[1] - b.lo[1] + RT_BY) / RT_BY, 1); }
 
-template <int HX, int HY>
+template <int HX, int HY, int BY = RT_BY>
 struct Tile {
-    static constexpr int PX = RT_BX + 2 * HX, PY = RT_BY + 2 * HY, SIZE = PX * PY;
-    static constexpr int NROWCELLS = 2 * HY * PX, NHALO = NROWCELLS + 2 * HX * RT_BY;
+    static constexpr int PX = RT_BX + 2 * HX, PY = BY + 2 * HY, SIZE = PX * PY;
+    static constexpr int NROWCELLS = 2 * HY * PX, NHALO = NROWCELLS + 2 * HX * BY;
     double *s;
     // value at tile-relative offset (di,dj) from this thread's own point
     __device__ __forceinline__ double at(int tx, int ty, int di, int dj) const { return s[(ty + HY + dj) * PX + (tx + HX + di)]; }
@@ -27,15 +27,21 @@ struct Tile {
     {
         s[(ty + HY) * PX + (tx + HX)] = c;
         if (NHALO > 0) {
-            for (int t = ty * RT_BX + tx; t < NHALO; t += RT_BX * RT_BY) {
+            for (int t = ty * RT_BX + tx; t < NHALO; t += RT_BX * BY) {
                 int x, y;
-                if (t < NROWCELLS) { const int r = t / PX; x = t - r * PX; y = r < HY ? r : RT_BY + r; }
+                if (t < NROWCELLS) { const int r = t / PX; x = t - r * PX; y = r < HY ? r : BY + r; }
                 else { const int u = t - NROWCELLS; constexpr int W2 = 2 * HX > 0 ? 2 * HX : 1; const int r = u / W2; const int xx = u - r * W2; y = HY + r; x = xx < HX ? xx : RT_BX + xx; }
                 const int gi = i0 - HX + x, gj = j0 - HY + y;
                 if (gi >= a.lo0 && gi <= a.hi0 && gj >= a.lo1 && gj <= a.hi1) s[y * PX + x] = a(gi, gj, k);
             }
         }
     }
+};
+// array-like view of a staged tile: v(i,j,k) with GLOBAL indices (k ignored), so stencil code written for A4 runs unchanged
+template <int HX, int HY, int BY = RT_BY>
+struct TView {
+    const double *s; int i0, j0;
+    __device__ __forceinline__ double operator()(int i, int j, int) const { return s[(j - j0 + HY) * (RT_BX + 2 * HX) + (i - i0 + HX)]; }
 };
 // Software-pipelined form: a thread's halo cell is fixed for the whole kernel, so it is located once (HaloCell), its value
 // for level k+1 is fetched into a register while level k is being computed, and put() writes own value + halo value into LDS

@@ -8,7 +8,8 @@ struct MixR { double pm_on_pn, pn_on_pm, a1, a0, b1, b0, on_r, om_r, visc; };
 struct MixP { double pmon_p, pnom_p, m125, c1, c0, d1, d0, om_p, on_p, visc; };
 
 // rho point (i,j): REMORA_uv3dmix.cpp:48-59 (UFx) and :103-115 (VFe)
-__device__ __forceinline__ MixR mix_r_metrics(const A4 &pm, const A4 &pn, const A4 &visc2_r, int i, int j)
+template <class PM, class PN, class VR>
+__device__ __forceinline__ MixR mix_r_metrics(const PM &pm, const PN &pn, const VR &visc2_r, int i, int j)
 {
     MixR r;
     const double pm0 = pm(i, j, 0), pn0 = pn(i, j, 0);
@@ -19,13 +20,15 @@ __device__ __forceinline__ MixR mix_r_metrics(const A4 &pm, const A4 &pn, const 
     r.visc = visc2_r(i, j, 0);
     return r;
 }
-__device__ __forceinline__ double mix_r_cff(const MixR &r, const A4 &Hz, const A4 &u, const A4 &v, int i, int j, int k)
+template <class H, class U, class V>
+__device__ __forceinline__ double mix_r_cff(const MixR &r, const H &Hz, const U &u, const V &v, int i, int j, int k)
 {
     return 0.5 * Hz(i, j, k) * (r.pm_on_pn * (r.a1 * u(i + 1, j, k) - r.a0 * u(i, j, k)) -
                                 r.pn_on_pm * (r.b1 * v(i, j + 1, k) - r.b0 * v(i, j, k)));
 }
 // psi point (i,j): REMORA_uv3dmix.cpp:61-78 (UFe) and :117-134 (VFx)
-__device__ __forceinline__ MixP mix_p_metrics(const A4 &pm, const A4 &pn, const A4 &visc2_p, const A4 &mskp, int i, int j)
+template <class PM, class PN, class VP, class MP>
+__device__ __forceinline__ MixP mix_p_metrics(const PM &pm, const PN &pn, const VP &visc2_p, const MP &mskp, int i, int j)
 {
     MixP p;
     const double spm = pm(i - 1, j - 1, 0) + pm(i - 1, j, 0) + pm(i, j - 1, 0) + pm(i, j, 0);
@@ -38,7 +41,8 @@ __device__ __forceinline__ MixP mix_p_metrics(const A4 &pm, const A4 &pn, const 
     p.visc = visc2_p(i, j, 0);
     return p;
 }
-__device__ __forceinline__ double mix_p_cff(const MixP &p, const A4 &Hz, const A4 &u, const A4 &v, int i, int j, int k)
+template <class H, class U, class V>
+__device__ __forceinline__ double mix_p_cff(const MixP &p, const H &Hz, const U &u, const V &v, int i, int j, int k)
 {
     return p.m125 * (Hz(i - 1, j, k) + Hz(i, j, k) + Hz(i - 1, j - 1, k) + Hz(i, j - 1, k)) *
            (p.pmon_p * (p.c1 * v(i, j, k) - p.c0 * v(i - 1, j, k)) + p.pnom_p * (p.d1 * u(i, j, k) - p.d0 * u(i, j - 1, k)));
