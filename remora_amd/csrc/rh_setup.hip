@@ -7,6 +7,7 @@
 // with the same per-expression operation order (build with -ffp-contract=off), so results are bit-identical to the
 // pass-by-pass form.
 #include "rh_common.h"
+#include "rh_tile.h"
 
 // ------------------------------------------------------------------------------------------------------------------
 // bottom stress, REMORA_setup_step.cpp:115-137
@@ -475,8 +476,8 @@ extern "C" int rh_t3dmix(rh_ctx *c, rh_box bx, rh_array4 state, rh_array4 state_
 // with surface and bottom stress.  UFx/UFe/VFx/VFe/FC never touch memory.
 struct UVGeom { int dlox, dhix, dloy, dhiy, perx, pery; };
 
-template <int C2>
-__device__ __forceinline__ double f_UFx(const A4 &u, const A4 &Hu, int i, int j, int k, const UVGeom &g)
+template <int C2, class TA, class TB>
+__device__ __forceinline__ double f_UFx(const TA &u, const TB &Hu, int i, int j, int k, const UVGeom &g)
 {
     if (C2) return 0.25 * (u(i, j, k) + u(i + 1, j, k)) * (Hu(i, j, k) + Hu(i + 1, j, k));
     const double Gadv = -0.25;
@@ -491,8 +492,8 @@ __device__ __forceinline__ double f_UFx(const A4 &u, const A4 &Hu, int i, int j,
     const double Huon_avg = (h0 + hp);
     return 0.25 * (cff1 + Gadv * cff) * (Huon_avg + 0.5 * Gadv * (Huxx_i + Huxx_ip1));
 }
-template <int C2>
-__device__ __forceinline__ double f_UFe(const A4 &u, const A4 &Hv, int i, int j, int k, const UVGeom &g)
+template <int C2, class TA, class TB>
+__device__ __forceinline__ double f_UFe(const TA &u, const TB &Hv, int i, int j, int k, const UVGeom &g)
 {
     if (C2) return 0.25 * (u(i, j - 1, k) + u(i, j, k)) * (Hv(i - 1, j, k) + Hv(i, j, k));
     const double Gadv = -0.25;
@@ -507,8 +508,8 @@ __device__ __forceinline__ double f_UFe(const A4 &u, const A4 &Hv, int i, int j,
     const double Hvxx_i = hm - 2.0 * h0 + hp, Hvxx_im1 = hmm - 2.0 * hm + h0;
     return 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * (Hvxx_i + Hvxx_im1));
 }
-template <int C2>
-__device__ __forceinline__ double f_VFx(const A4 &v, const A4 &Hu, int i, int j, int k, const UVGeom &g)
+template <int C2, class TA, class TB>
+__device__ __forceinline__ double f_VFx(const TA &v, const TB &Hu, int i, int j, int k, const UVGeom &g)
 {
     if (C2) return 0.25 * (v(i - 1, j, k) + v(i, j, k)) * (Hu(i, j - 1, k) + Hu(i, j, k));
     const double Gadv = -0.25;
@@ -523,8 +524,8 @@ __device__ __forceinline__ double f_VFx(const A4 &v, const A4 &Hu, int i, int j,
     const double Huee_j = hm - 2.0 * h0 + hp, Huee_jm1 = hmm - 2.0 * hm + h0;
     return 0.25 * (cff1 + Gadv * cff) * (cff2 + Gadv * 0.5 * (Huee_j + Huee_jm1));
 }
-template <int C2>
-__device__ __forceinline__ double f_VFe(const A4 &v, const A4 &Hv, int i, int j, int k, const UVGeom &g)
+template <int C2, class TA, class TB>
+__device__ __forceinline__ double f_VFe(const TA &v, const TB &Hv, int i, int j, int k, const UVGeom &g)
 {
     if (C2) return 0.25 * (v(i, j, k) + v(i, j + 1, k)) * (Hv(i, j, k) + Hv(i, j + 1, k));
     const double Gadv = -0.25;
@@ -615,6 +616,125 @@ __global__ void k_rhs_uv_3d(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv,
         rvfrc(i, j, 0) = frc;
     }
 }
+// ---- LDS-tiled, software-pipelined form of k_rhs_uv_3d (same arithmetic).  uold, vold, Huon, Hvom, W(k+1) are staged with a
+// halo of 2 and Hz with a halo of 1; each thread loads its own point of every field once per level, one level ahead of its use;
+// the vertical flux uses a 4-level register window.  k-invariant per-thread values (Coriolis factors, stress terms) sit in LDS.
+__device__ __forceinline__ double win_FCw(double qm1, double q0, double qp1, double qp2, double wpart, int kk, int N, int c2, double w0, double w1)
+{   // vertical momentum flux through face kk from the window q(kk-2), q(kk-1), q(kk), q(kk+1) = qm1, q0, qp1, qp2  (:168-198, :319-345)
+    if (kk <= 0 || kk >= N + 1) return 0.0;
+    if (c2) return 0.25 * (q0 + qp1) * (w0 + w1);
+    const double cff1 = 9.0 / 16.0, cff2 = 1.0 / 16.0;
+    if (kk > 1 && kk <= N - 1) return (cff1 * (q0 + qp1) - cff2 * (qm1 + qp2)) * wpart;
+    if (kk == N) return (cff1 * (q0 + qp1) - cff2 * (qm1 + qp1)) * wpart;       // q(N-1)+q(N), q(N-2)+q(N)
+    return (cff1 * (q0 + qp1) - cff2 * (q0 + qp2)) * wpart;                      // kk == 1: q(0)+q(1), q(0)+q(2)
+}
+template <int C2>
+__global__ void __launch_bounds__(RT_BX * RT_BY, 2)
+k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4 rvfrc, A4 sustr, A4 svstr, A4 bustr, A4 bvstr,
+               A4 Huon, A4 Hvom, A4 pm, A4 pn, A4 W, A4 Hz, A4 fcor, int use_cor, int nrhs, int N, UVGeom g)
+{
+    typedef Tile<2, 2> T2; typedef Tile<1, 1> T1; typedef TView<2, 2> V2; typedef TView<1, 1> V1;
+    constexpr int NT = RT_BX * RT_BY, SET = 5 * T2::SIZE + T1::SIZE, NINV = 8;
+    __shared__ double lds[2 * SET + NINV * NT];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
+    double *inv = lds + 2 * SET + tid;
+    const int i0 = un.lo0 + (int)blockIdx.x * RT_BX, j0 = un.lo1 + (int)blockIdx.y * RT_BY;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool au = inb2(xb, i, j), av = inb2(yb, i, j);
+    // k-invariants: Coriolis factors fomn at (i,j), (i-1,j), (i,j-1); stress terms; running vertical integrals
+    {
+        double fm0 = 0.0, fmx = 0.0, fmy = 0.0, su_t = 0.0, su_b = 0.0, sv_t = 0.0, sv_b = 0.0;
+        if (au || av) { if (use_cor) fm0 = fcor(i, j, 0) * (1.0 / (pm(i, j, 0) * pn(i, j, 0))); }
+        if (au) {
+            if (use_cor) fmx = fcor(i - 1, j, 0) * (1.0 / (pm(i - 1, j, 0) * pn(i - 1, j, 0)));
+            const double om_u = 2.0 / (pm(i - 1, j, 0) + pm(i, j, 0)), on_u = 2.0 / (pn(i - 1, j, 0) + pn(i, j, 0));
+            const double cffs = om_u * on_u;
+            su_t = sustr(i, j, 0) * cffs; su_b = -bustr(i, j, 0) * cffs;
+        }
+        if (av) {
+            if (use_cor) fmy = fcor(i, j - 1, 0) * (1.0 / (pm(i, j - 1, 0) * pn(i, j - 1, 0)));
+            const double om_v = 2.0 / (pm(i, j - 1, 0) + pm(i, j, 0)), on_v = 2.0 / (pn(i, j - 1, 0) + pn(i, j, 0));
+            const double cffs = om_v * on_v;
+            sv_t = svstr(i, j, 0) * cffs; sv_b = -bvstr(i, j, 0) * cffs;
+        }
+        inv[0 * NT] = fm0; inv[1 * NT] = fmx; inv[2 * NT] = fmy; inv[3 * NT] = su_t; inv[4 * NT] = su_b; inv[5 * NT] = sv_t; inv[6 * NT] = sv_b;
+    }
+    double frcu = au ? rufrc(i, j, 0) : 0.0, frcv = av ? rvfrc(i, j, 0) : 0.0;
+    const HaloCell hu = halo_cell<2, 2>(uold, i0, j0, tx, ty), hv = halo_cell<2, 2>(vold, i0, j0, tx, ty), hHu = halo_cell<2, 2>(Huon, i0, j0, tx, ty),
+                   hHv = halo_cell<2, 2>(Hvom, i0, j0, tx, ty), hW = halo_cell<2, 2>(W, i0, j0, tx, ty), hHz = halo_cell<1, 1>(Hz, i0, j0, tx, ty);
+    // vertical windows q(k-1), q(k), q(k+1), q(k+2) of the own point
+    double um1 = 0.0, u0 = ld_in(uold, i, j, 0), up1 = ld_in(uold, i, j, 1), up2 = (2 <= N) ? ld_in(uold, i, j, 2) : 0.0;
+    double vm1 = 0.0, v0 = ld_in(vold, i, j, 0), vp1 = ld_in(vold, i, j, 1), vp2 = (2 <= N) ? ld_in(vold, i, j, 2) : 0.0;
+    double Hu0 = ld_in(Huon, i, j, 0), Hv0 = ld_in(Hvom, i, j, 0), hz = ld_in(Hz, i, j, 0), W1 = ld_in(W, i, j, 1);
+    double uh = halo_ld(uold, hu, 0), vh = halo_ld(vold, hv, 0), Huh = halo_ld(Huon, hHu, 0), Hvh = halo_ld(Hvom, hHv, 0),
+           Wh = halo_ld(W, hW, 1), hzh = halo_ld(Hz, hHz, 0);
+    double rru = au ? ru(i, j, 0, nrhs) : 0.0, rrv = av ? rv(i, j, 0, nrhs) : 0.0;
+    double FCu = 0.0, FCv = 0.0;
+    for (int k = 0; k <= N; k++) {
+        double *set = lds + (k & 1) * SET;
+        double *su = set, *sv = su + T2::SIZE, *sHu = sv + T2::SIZE, *sHv = sHu + T2::SIZE, *sW = sHv + T2::SIZE, *sHz = sW + T2::SIZE;
+        tile_put<2, 2>(su, tx, ty, u0, hu, uh); tile_put<2, 2>(sv, tx, ty, v0, hv, vh);
+        tile_put<2, 2>(sHu, tx, ty, Hu0, hHu, Huh); tile_put<2, 2>(sHv, tx, ty, Hv0, hHv, Hvh);
+        tile_put<2, 2>(sW, tx, ty, W1, hW, Wh); tile_put<1, 1>(sHz, tx, ty, hz, hHz, hzh);
+        // ---- prefetch level k+1
+        const bool more = k + 1 <= N;
+        const double u_n = (k + 3 <= N) ? ld_in(uold, i, j, k + 3) : 0.0, v_n = (k + 3 <= N) ? ld_in(vold, i, j, k + 3) : 0.0;
+        const double Hu0_n = more ? ld_in(Huon, i, j, k + 1) : 0.0, Hv0_n = more ? ld_in(Hvom, i, j, k + 1) : 0.0, hz_n = more ? ld_in(Hz, i, j, k + 1) : 0.0;
+        const double W1_n = more ? ld_in(W, i, j, k + 2) : 0.0;
+        const double uh_n = more ? halo_ld(uold, hu, k + 1) : 0.0, vh_n = more ? halo_ld(vold, hv, k + 1) : 0.0;
+        const double Huh_n = more ? halo_ld(Huon, hHu, k + 1) : 0.0, Hvh_n = more ? halo_ld(Hvom, hHv, k + 1) : 0.0;
+        const double Wh_n = more ? halo_ld(W, hW, k + 2) : 0.0, hzh_n = more ? halo_ld(Hz, hHz, k + 1) : 0.0;
+        const double rru_n = (more && au) ? ru(i, j, k + 1, nrhs) : 0.0, rrv_n = (more && av) ? rv(i, j, k + 1, nrhs) : 0.0;
+        __syncthreads();
+        const V2 tu{su, i0, j0}, tv{sv, i0, j0}, tHu{sHu, i0, j0}, tHv{sHv, i0, j0}, tW{sW, i0, j0};
+        const V1 tHz{sHz, i0, j0};
+        if (au) {
+            double r = rru;
+            if (use_cor) {
+                const double UFx_i = 0.5 * hz * inv[0 * NT] * (v0 + tv(i, j + 1, 0));
+                const double UFx_im1 = 0.5 * tHz(i - 1, j, 0) * inv[1 * NT] * (tv(i - 1, j, 0) + tv(i - 1, j + 1, 0));
+                r += 0.5 * (UFx_i + UFx_im1);
+            }
+            r -= ((f_UFx<C2>(tu, tHu, i, j, 0, g) - f_UFx<C2>(tu, tHu, i - 1, j, 0, g)) +
+                  (f_UFe<C2>(tu, tHv, i, j + 1, 0, g) - f_UFe<C2>(tu, tHv, i, j, 0, g)));
+            const double w0 = W1, w1 = tW(i - 1, j, 0);
+            const double wpart = C2 ? 0.0 : ((9.0 / 16.0) * (w0 + w1) - (1.0 / 16.0) * (tW(i + 1, j, 0) + tW(i - 2, j, 0)));
+            const double FCk1 = win_FCw(um1, u0, up1, up2, wpart, k + 1, N, C2, w0, w1);
+            const double cff = FCk1 - FCu;
+            r -= cff;
+            ru(i, j, k, nrhs) = r;
+            frcu += r;
+            const double c1 = (k == N) ? inv[3 * NT] : 0.0, c2 = (k == 0) ? inv[4 * NT] : 0.0;
+            frcu += c1 + c2;
+            FCu = FCk1;
+        }
+        if (av) {
+            double r = rrv;
+            if (use_cor) {
+                const double VFe_j = 0.5 * hz * inv[0 * NT] * (u0 + tu(i + 1, j, 0));
+                const double VFe_jm1 = 0.5 * tHz(i, j - 1, 0) * inv[2 * NT] * (tu(i, j - 1, 0) + tu(i + 1, j - 1, 0));
+                r -= 0.5 * (VFe_j + VFe_jm1);
+            }
+            r -= ((f_VFx<C2>(tv, tHu, i + 1, j, 0, g) - f_VFx<C2>(tv, tHu, i, j, 0, g)) +
+                  (f_VFe<C2>(tv, tHv, i, j, 0, g) - f_VFe<C2>(tv, tHv, i, j - 1, 0, g)));
+            const double w0 = W1, w1 = tW(i, j - 1, 0);
+            const double wpart = C2 ? 0.0 : ((9.0 / 16.0) * (w0 + w1) - (1.0 / 16.0) * (tW(i, j + 1, 0) + tW(i, j - 2, 0)));
+            const double FCk1 = win_FCw(vm1, v0, vp1, vp2, wpart, k + 1, N, C2, w0, w1);
+            const double cff = FCk1 - FCv;
+            r -= cff;
+            rv(i, j, k, nrhs) = r;
+            frcv += r;
+            const double c1 = (k == N) ? inv[5 * NT] : 0.0, c2 = (k == 0) ? inv[6 * NT] : 0.0;
+            frcv += c1 + c2;
+            FCv = FCk1;
+        }
+        um1 = u0; u0 = up1; up1 = up2; up2 = u_n; vm1 = v0; v0 = vp1; vp1 = vp2; vp2 = v_n;
+        Hu0 = Hu0_n; Hv0 = Hv0_n; hz = hz_n; W1 = W1_n; uh = uh_n; vh = vh_n; Huh = Huh_n; Hvh = Hvh_n; Wh = Wh_n; hzh = hzh_n; rru = rru_n; rrv = rrv_n;
+    }
+    if (au) rufrc(i, j, 0) = frcu;
+    if (av) rvfrc(i, j, 0) = frcv;
+}
+
 extern "C" int rh_rhs_uv_3d(rh_ctx *c, rh_box xbx, rh_box ybx, rh_array4 uold, rh_array4 vold, rh_array4 ru, rh_array4 rv,
                             rh_array4 rufrc, rh_array4 rvfrc, rh_array4 sustr, rh_array4 svstr, rh_array4 bustr, rh_array4 bvstr,
                             rh_array4 Huon, rh_array4 Hvom, rh_array4 pm, rh_array4 pn, rh_array4 W, rh_array4 Hz, rh_array4 fcor,
@@ -636,11 +756,15 @@ extern "C" int rh_rhs_uv_3d(rh_ctx *c, rh_box xbx, rh_box ybx, rh_array4 uold, r
     if (use_coriolis) { RH_NEED(fcor, bx_growlo_i(x2)); RH_NEED(fcor, bx_growlo_j(y2)); }
     UVGeom g = {c->dom.lo[0], c->dom.hi[0], c->dom.lo[1], c->dom.hi[1], c->prm.periodic[0], c->prm.periodic[1]};
     const rh_box un = bx_union(xbx, ybx);
-#define RH_UV(C2) k_rhs_uv_3d<C2><<<grid2(un), rh_block(), 0, c->stream>>>(mkB(xbx), mkB(ybx), mkB(un), mkA(uold), mkA(vold), mkA(ru), mkA(rv), \
+#define RH_UVARGS mkB(xbx), mkB(ybx), mkB(un), mkA(uold), mkA(vold), mkA(ru), mkA(rv), \
         mkA(rufrc), mkA(rvfrc), mkA(sustr), mkA(svstr), mkA(bustr), mkA(bvstr), mkA(Huon), mkA(Hvom), mkA(pm), mkA(pn), mkA(W), mkA(Hz), mkA(fcor), \
-        use_coriolis, nrhs, N, g)
-    if (c->prm.uv_c2) RH_UV(1); else RH_UV(0);
-#undef RH_UV
+        use_coriolis, nrhs, N, g
+    if (c->unfused) {           // RH_UNFUSED=1: the direct-from-global form, kept as the A/B reference of the tiled kernel
+        if (c->prm.uv_c2) k_rhs_uv_3d<1><<<grid2(un), rh_block(), 0, c->stream>>>(RH_UVARGS); else k_rhs_uv_3d<0><<<grid2(un), rh_block(), 0, c->stream>>>(RH_UVARGS);
+    } else {
+        if (c->prm.uv_c2) k_rhs_uv_tiled<1><<<rt_grid(un), rt_block(), 0, c->stream>>>(RH_UVARGS); else k_rhs_uv_tiled<0><<<rt_grid(un), rt_block(), 0, c->stream>>>(RH_UVARGS);
+    }
+#undef RH_UVARGS
     RH_LAUNCH_CHECK(); return 0;
 }
 
