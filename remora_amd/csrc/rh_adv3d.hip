@@ -158,6 +158,120 @@ __global__ void k_vert_visc(B3 bx, int ioff, int joff, A4 phi, A4 Hz, A4 Akv, A4
         DC_up = DC; DCs_up = DCs;
     }
 }
+// ---- vert_visc_3d with the tridiagonal coefficients in LDS.  One wavefront per block, one column per lane; CF(k), DC(k) of
+// the elimination live in LDS ([k][lane], conflict-free) instead of a global work-space slab, which removes 4 of the 11
+// doubles per cell the slab form moves.  The column-neighbour (i-1) of a u column comes from the neighbouring lane by a
+// cross-lane shuffle (only lane 0 loads it).  Loads are independent of the recurrence, so they are issued VV_U levels ahead
+// of their use (explicit double-buffered batches): with ~3 wavefronts per CU (LDS-limited) that is what hides HBM latency.
+#define VV_U 8
+template <int IO, int JO>
+__global__ void __launch_bounds__(64)
+k_vert_visc_lds(B3 bx, A4 phi, A4 Hz, A4 Akv, int N, double dt)
+{
+    extern __shared__ double vv_lds[];
+    const int lane = threadIdx.x;
+    double *sCF = vv_lds + lane, *sDC = vv_lds + (size_t)(N + 2) * 64 + lane;      // s[k * 64]
+    const int i = bx.lo0 + (int)blockIdx.x * 64 + lane, j = bx.lo1 + (int)blockIdx.y;
+    const bool act = i <= bx.hi0;
+    const int ic = act ? i : bx.hi0;                       // inactive lanes shadow the last column (no stores)
+    const int jj = j - JO;
+    const bool edge = (IO == 1) && (lane == 0);            // the only lane whose i-1 neighbour is not in the wave
+    const double sixth = 1.0 / 6.0, third = 1.0 / 3.0;
+    // second point of the face average: (i-1,j) via shuffle, (i,j-1) via its own load, or the same point (tracers)
+    auto second = [&](double own, double extra) -> double {
+        if (IO == 1) { const double s = __shfl_up(own, 1); return edge ? extra : s; }
+        if (JO == 1) return extra;
+        return own;
+    };
+    auto ld2 = [&](const A4 &a, int k) -> double {       // the load that `second` may need
+        if (IO == 1) return edge ? a(ic - 1, j, k) : 0.0;
+        if (JO == 1) return a(ic, jj, k);
+        return 0.0;
+    };
+    // ---- upward elimination, :51-75
+    double Hzk_m, AK_m, AK_0, phi_m;
+    {
+        const double h = Hz(ic, j, 0), hx = ld2(Hz, 0), a0 = Akv(ic, j, 0), a0x = ld2(Akv, 0), a1 = Akv(ic, j, 1), a1x = ld2(Akv, 1);
+        Hzk_m = 0.5 * (second(h, hx) + h);
+        AK_m = 0.5 * (second(a0, a0x) + a0);
+        AK_0 = 0.5 * (second(a1, a1x) + a1);
+        phi_m = phi(ic, j, 0);
+    }
+    double CFp = 0.0, DCp = 0.0;
+    double nP[VV_U], nH[VV_U], nHx[VV_U], nA[VV_U], nAx[VV_U];
+#pragma unroll
+    for (int u = 0; u < VV_U; u++) {
+        const int k = 1 + u; const bool ok = k <= N;
+        nP[u] = ok ? phi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
+        nA[u] = ok ? Akv(ic, j, k + 1) : 0.0; nAx[u] = ok ? ld2(Akv, k + 1) : 0.0;
+    }
+    for (int kb = 1; kb <= N; kb += VV_U) {
+        double cP[VV_U], cH[VV_U], cHx[VV_U], cA[VV_U], cAx[VV_U];
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) { cP[u] = nP[u]; cH[u] = nH[u]; cHx[u] = nHx[u]; cA[u] = nA[u]; cAx[u] = nAx[u]; }
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) {                 // next batch in flight while this one is eliminated
+            const int k = kb + VV_U + u; const bool ok = k <= N;
+            nP[u] = ok ? phi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
+            nA[u] = ok ? Akv(ic, j, k + 1) : 0.0; nAx[u] = ok ? ld2(Akv, k + 1) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) {
+            const int k = kb + u;
+            const double Hzk_0 = 0.5 * (second(cH[u], cHx[u]) + cH[u]);
+            const double AK_p = 0.5 * (second(cA[u], cAx[u]) + cA[u]);
+            if (k <= N) {
+                const double phi_0 = cP[u];
+                const double oHzkm1 = 1.0 / Hzk_m;
+                const double oHz = 1.0 / Hzk_0;
+                const double FC = sixth * Hzk_m - dt * AK_m / Hzk_m;
+                double CF = sixth * Hzk_0 - dt * AK_p / Hzk_0;
+                const double BC = third * (Hzk_m + Hzk_0) + dt * AK_0 * (oHzkm1 + oHz);
+                const double cff = 1.0 / (BC - FC * CFp);
+                CF *= cff;
+                const double DC = cff * (phi_0 - phi_m - FC * DCp);
+                sCF[k * 64] = CF; sDC[k * 64] = DC;
+                CFp = CF; DCp = DC; Hzk_m = Hzk_0; AK_m = AK_0; AK_0 = AK_p; phi_m = phi_0;
+            }
+        }
+    }
+    // ---- back-substitution fused with the update, :81-106.  Here AK_0 = AK(N+1).
+    double DC_up = 0.0, DCs_up = DC_up * AK_0;
+#pragma unroll
+    for (int u = 0; u < VV_U; u++) {
+        const int k = N - u; const bool ok = k >= 0;
+        nP[u] = ok ? phi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
+        nA[u] = ok ? Akv(ic, j, k) : 0.0; nAx[u] = ok ? ld2(Akv, k) : 0.0;
+    }
+    for (int kb = N; kb >= 0; kb -= VV_U) {
+        double cP[VV_U], cH[VV_U], cHx[VV_U], cA[VV_U], cAx[VV_U];
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) { cP[u] = nP[u]; cH[u] = nH[u]; cHx[u] = nHx[u]; cA[u] = nA[u]; cAx[u] = nAx[u]; }
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) {
+            const int k = kb - VV_U - u; const bool ok = k >= 0;
+            nP[u] = ok ? phi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
+            nA[u] = ok ? Akv(ic, j, k) : 0.0; nAx[u] = ok ? ld2(Akv, k) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) {
+            const int k = kb - u;
+            const double Hzk = 0.5 * (second(cH[u], cHx[u]) + cH[u]);
+            const double AKk = 0.5 * (second(cA[u], cAx[u]) + cA[u]);
+            if (k >= 0) {
+                double DC;
+                if (k >= 1) { DC = sDC[k * 64]; DC -= sCF[k * 64] * DC_up; }
+                else DC = 0.0;
+                const double DCs = DC * AKk;
+                const double oHz = 1.0 / Hzk;
+                const double cff = dt * oHz * (DCs_up - DCs);
+                if (act) phi(i, j, k) = cP[u] + cff;
+                DC_up = DC; DCs_up = DCs;
+            }
+        }
+    }
+}
+
 extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 phi, rh_array4 Hz, rh_array4 Akv, int N, double dt)
 {
     TScope t(c, "vert_visc_3d");
@@ -167,7 +281,14 @@ extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_
     rh_box bw = bs; bw.hi[2] = N + 1;
     rh_box pw = phi_bx; pw.hi[2] = N + 1;
     RH_NEED(phi, phi_bx); RH_NEED(Hz, bs); RH_NEED(Akv, bw); RH_NEED(c->wCF, pw); RH_NEED(c->wDC, pw);
-    k_vert_visc<<<grid2(phi_bx), rh_block(), 0, c->stream>>>(mkB(phi_bx), ioff, joff, mkA(phi), mkA(Hz), mkA(Akv), mkA(c->wCF), mkA(c->wDC), N, dt);
+    const size_t lds_bytes = sizeof(double) * 2 * (size_t)(N + 2) * 64;
+    if (!c->unfused && lds_bytes <= 64 * 1024) {         // coefficients in LDS (up to 62 levels at >= 2 wavefronts per CU)
+        const dim3 grid((phi_bx.hi[0] - phi_bx.lo[0] + 64) / 64, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);
+        if (ioff) k_vert_visc_lds<1, 0><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), mkA(Hz), mkA(Akv), N, dt);
+        else if (joff) k_vert_visc_lds<0, 1><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), mkA(Hz), mkA(Akv), N, dt);
+        else k_vert_visc_lds<0, 0><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), mkA(Hz), mkA(Akv), N, dt);
+    } else                                               // deeper columns: coefficients in the global work-space slab
+        k_vert_visc<<<grid2(phi_bx), rh_block(), 0, c->stream>>>(mkB(phi_bx), ioff, joff, mkA(phi), mkA(Hz), mkA(Akv), mkA(c->wCF), mkA(c->wDC), N, dt);
     RH_LAUNCH_CHECK(); return 0;
 }
 
