@@ -80,6 +80,8 @@ int rh_fail(const char *fmt, ...);
     (arr).lo[0],(arr).hi[0],(arr).lo[1],(arr).hi[1],(arr).lo[2],(arr).hi[2],(box).lo[0],(box).hi[0],(box).lo[1],(box).hi[1],(box).lo[2],(box).hi[2], __FILE__, __LINE__); } while (0)
 
 struct BCRec3 { int lo[3], hi[3]; };
+void *bc_queue_new();
+void bc_queue_delete(void *q);
 
 // a view plus what AMReX keeps in the MultiFab: valid box, index type, ghost widths
 struct MFV { rh_array4 a; rh_box valid; int ix[3]; int ng[3]; };
@@ -105,8 +107,10 @@ struct rh_ctx {
     std::vector<std::string> tnames; std::map<std::string,int> tslot;
     std::vector<std::vector<std::pair<hipEvent_t,hipEvent_t>>> tev;
     std::vector<hipEvent_t> evpool;
+    void *bcq = nullptr; int bc_defer = 0;                     // queued physical-BC passes (rh_halo.hip)
     bool unfused = false;            // RH_UNFUSED=1: drivers call the per-leaf entry points instead of the fused kernels (A/B parity)
     bool poison = false;             // RH_POISON=1: NaN-fill the work space at the start of every step (stale-read detector)
+    ~rh_ctx() { if (bcq) bc_queue_delete(bcq); }
 };
 
 // timing scope: records events around a kernel group when enabled
@@ -122,6 +126,12 @@ MFV  mfv(const rh_ctx *c, const rh_array4 &a, int ix0, int ix1, int ix2);
 int  halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp);
 int  halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill);
 int  halo_fillpatch(rh_ctx *c, const MFV &m, const rh_array4 &msk, int bccomp, int icomp, int ncomp);
+// BC passes issued between bc_begin and the matching bc_end are queued and flushed as one launch per dependency level; only
+// ghost-fill calls may sit inside such a scope (any other kernel on the same arrays would overtake the queued passes)
+void bc_begin(rh_ctx *c);
+int  bc_end(rh_ctx *c);
+int  bc_flush(rh_ctx *c);
+struct BcScope { rh_ctx *c; BcScope(rh_ctx *ctx) : c(ctx) { bc_begin(c); } ~BcScope() { if (c) (void)bc_end(c); } int end() { rh_ctx *x = c; c = nullptr; return bc_end(x); } };
 // kernels without a C entry point of their own (rh_setup.hip, rh_adv3d.hip, rh_step2d.hip)
 int  launch_bstress(rh_ctx *c, rh_state *s);
 int  launch_massflux_old(rh_ctx *c, rh_state *s);

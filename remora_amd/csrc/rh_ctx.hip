@@ -289,6 +289,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
         }
     }
     for (int d = 0; d < 2; d++) if (prm->periodic[d] && (c->dom.hi[d] - c->dom.lo[d] + 1) < 4) return bad("periodic direction shorter than the ghost width");
+    c->bcq = bc_queue_new();
     c->nfast = set_weights(prm->ndtfast, c->w1, c->w2);
     init_bcs(c);
     c->unfused = getenv("RH_UNFUSED") && atoi(getenv("RH_UNFUSED")) != 0;

@@ -24,10 +24,11 @@ static int set_analytical_vmix(rh_ctx *c, rh_state *s)
 {
     TScope t(c, "vmix");
     RH_TRY(launch_vmix(c, s));
+    BcScope bcs(c);
     RH_TRY(halo_fillpatch(c, mfv(c, s->Akv, 0, 0, 1), s->mskr, RH_BCV_ZVEL, 0, 1));
     // the reference loops over NCONS but fills component 0 each time (REMORA.cpp:570-572): once is the same
     RH_TRY(halo_fillpatch(c, mfv(c, s->Akt, 0, 0, 1), s->mskr, RH_BCV_ZVEL, 0, 1));
-    return 0;
+    return bcs.end();
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -42,6 +43,7 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     if (c->poison) { RH_HIP(hipMemsetAsync(c->d_work, 0xFF, c->work_bytes, c->stream)); }
     {
         TScope t(c, "halo");
+        BcScope bcs(c);
         RH_TRY(halo_fill_boundary(c, mfv(c, s->cons_old, 0, 0, 0), 0, RH_NCONS));                  // :25-28
         RH_TRY(halo_fill_boundary(c, mfv(c, s->xvel_old, 1, 0, 0), 0, 1));
         RH_TRY(halo_fill_boundary(c, mfv(c, s->yvel_old, 0, 1, 0), 0, 1));
@@ -49,6 +51,7 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
         RH_TRY(halo_fill_boundary(c, mfv(c, s->cons_new, 0, 0, 0), 0, RH_NCONS));                  // :95-97
         RH_TRY(halo_fill_boundary(c, mfv(c, s->xvel_new, 1, 0, 0), 0, 1));
         RH_TRY(halo_fill_boundary(c, mfv(c, s->yvel_new, 0, 1, 0), 0, 1));
+        RH_TRY(bcs.end());
     }
     RH_TRY(dev_setval(c, s->rufrc, 0, s->rufrc.ncomp, 0.0)); RH_TRY(dev_setval(c, s->rvfrc, 0, s->rvfrc.ncomp, 0.0));
     if (iic == ntfirst) {                                                                          // :105-110
@@ -59,8 +62,10 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     {
         TScope t(c, "bstress");
         RH_TRY(launch_bstress(c, s));                                                              // :115-140
+        BcScope bcs(c);
         RH_TRY(halo_fillpatch(c, mfv(c, s->bustr, 1, 0, 0), s->msku, RH_BCV_U2D_SIMPLE, 0, 1));
         RH_TRY(halo_fillpatch(c, mfv(c, s->bvstr, 0, 1, 0), s->mskv, RH_BCV_V2D_SIMPLE, 0, 1));
+        RH_TRY(bcs.end());
     }
     { TScope t(c, "massflux_old"); RH_TRY(launch_massflux_old(c, s)); }                            // :187-197
     RH_TRY(rh_rho_eos(c, bx_grow(bx, 2, 2, 0), s->cons_old, c->rho, s->rhoA, s->rhoS, s->bvf, s->Hz, s->z_w, s->z_r, s->h, s->mskr, N));   // :200
@@ -82,9 +87,11 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     }
     {
         TScope t(c, "halo");
+        BcScope bcs(c);
         const MFV mW = mfv(c, c->W, 0, 0, 1);
         RH_TRY(halo_fill_boundary(c, mW, 0, 1));                                                   // :226-227
         RH_TRY(halo_physbc(c, mW, s->mskr, 0, 1, RH_BCV_ZVEL, 0));
+        RH_TRY(bcs.end());
     }
     const rh_box xbx = bx_nodal(bx, 0), ybx = bx_nodal(bx, 1);
     RH_TRY(rh_prsgrd(c, bx_grow(bx, 1, 1, 0), xbx, ybx, s->ru, s->rv, s->pn, s->pm, c->rho, c->P, s->Hz, s->z_r, s->z_w, s->msku, s->mskv, nrhs, N));
@@ -99,9 +106,11 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
                           s->pm, s->pn, s->mskp, nrhs, 0, dt));
     {
         TScope t(c, "halo");
+        BcScope bcs(c);
         RH_TRY(halo_fillpatch(c, mfv(c, s->sstore, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS));  // :363
         RH_TRY(halo_fill_boundary(c, mfv(c, s->Huon, 1, 0, 0), 0, 1));                             // :367-368
         RH_TRY(halo_fill_boundary(c, mfv(c, s->Hvom, 0, 1, 0), 0, 1));
+        RH_TRY(bcs.end());
     }
     return 0;
 }
@@ -121,8 +130,10 @@ static int advance_3d(rh_ctx *c, rh_state *s, int istep)
     RH_TRY(rh_vert_mean_3d(c, ybx, 0, 1, s->yvel_new, s->Hz, s->DV_avg1, s->pm, s->mskv, N));      // :150
     {
         TScope t(c, "halo");
+        BcScope bcs(c);
         RH_TRY(halo_physbc(c, mfv(c, s->xvel_new, 1, 0, 0), s->msku, 0, 1, RH_BCV_XVEL, 0));       // :154-155
         RH_TRY(halo_physbc(c, mfv(c, s->yvel_new, 0, 1, 0), s->mskv, 0, 1, RH_BCV_YVEL, 0));
+        RH_TRY(bcs.end());
     }
     RH_TRY(rh_update_massflux_3d(c, gbx2, 1, 0, s->xvel_new, s->ubar, s->Huon, s->Hz, s->pn, s->DU_avg1, s->DU_avg2, s->msku, N));   // :213
     RH_TRY(rh_update_massflux_3d(c, gbx2, 0, 1, s->yvel_new, s->vbar, s->Hvom, s->Hz, s->pm, s->DV_avg1, s->DV_avg2, s->mskv, N));   // :218
@@ -143,18 +154,22 @@ extern "C" int rh_advance_3d_ml(rh_ctx *c, rh_state *s, int istep)
     TScope tsc(c, "advance_3d_ml");
     {
         TScope t(c, "halo");
+        BcScope bcs(c);
         RH_TRY(halo_fill_boundary(c, mfv(c, s->xvel_new, 1, 0, 0), 0, 1));                         // :11-12
         RH_TRY(halo_fill_boundary(c, mfv(c, s->yvel_new, 0, 1, 0), 0, 1));
+        RH_TRY(bcs.end());
     }
     RH_TRY(advance_3d(c, s, istep));
     {
         TScope t(c, "halo");
+        BcScope bcs(c);
         RH_TRY(halo_fill_boundary(c, mfv(c, s->ubar, 1, 0, 0), 0, 3));                             // :33-38
         RH_TRY(halo_fill_boundary(c, mfv(c, s->vbar, 0, 1, 0), 0, 3));
         RH_TRY(halo_fillpatch(c, mfv(c, s->cons_new, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS)); // :45
         RH_TRY(halo_fill_boundary(c, mfv(c, s->xvel_new, 1, 0, 0), 0, 1));                         // :46-47
         RH_TRY(halo_fill_boundary(c, mfv(c, s->yvel_new, 0, 1, 0), 0, 1));
         RH_TRY(halo_fillpatch(c, mfv(c, s->zvel_new, 0, 0, 1), s->mskr, RH_BCV_ZVEL, 0, 1));       // :48
+        RH_TRY(bcs.end());
     }
     if (!c->prm.masks_all_one) RH_TRY(launch_mask_cons(c, s));                                     // :51-62 (x *= 1.0 is the identity)
     return 0;

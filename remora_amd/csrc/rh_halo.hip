@@ -86,11 +86,13 @@ __global__ void k_rows(A4 a, double *__restrict__ buf, int dir, int icomp, int n
     }
 }
 
+static int bc_flush_if_pending(rh_ctx *c, const double *p, long n);
 int halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp)
 {
     const int np = c->prm.nranks[1] < 1 ? 1 : c->prm.nranks[1];
     const int perx = c->prm.periodic[0], pery = (np == 1) ? c->prm.periodic[1] : 0;     // decomposed: j handled by the exchange
     if (icomp < 0 || icomp + ncomp > m.a.ncomp) return rh_fail("halo_fill_boundary: component range");
+    RH_TRY(bc_flush_if_pending(c, m.a.p, a4_size(m.a)));
     A4 a = mkA(m.a); B3 v = mkB(m.valid);
     const long NX = a.hi0 - a.lo0 + 1, NY = a.hi1 - a.lo1 + 1, vx = v.hi0 - v.lo0 + 1, vy = v.hi1 - v.lo1 + 1;
     if (vx <= 0 || vy <= 0 || !bx_contains(bx_of(m.a), m.valid)) return rh_fail("halo_fill_boundary: valid box not inside array");
@@ -126,23 +128,76 @@ int halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp)
     return 0;
 }
 
-// ---- one pass of a physical-BC routine over a (small) region -------------------------------------------------
+// ---- passes of the physical-BC routines over (small) regions ---------------------------------------------------
+// A BC routine is a chain of small passes (sides, then edges, then corners) whose order matters only where one pass reads or
+// overwrites what another wrote.  Passes are queued with the level of their deepest hazard (RAW / WAW / WAR against queued
+// passes on the same component) and flushed as ONE launch per level, 16 passes per launch: the three FillPatch calls that end
+// every barotropic call become 3 launches instead of ~28.
 enum { BCP_CONST = 0, BCP_COPY_I = 1, BCP_COPY_J = 2, BCP_CORNER = 3 };
-// dest(i,j,k) = val*msk | dest(si,j,k)*msk | dest(i,sj,k)*msk | 0.5*(dest(i,sj,k)+dest(si,j,k));  msk.p == null: no mask factor
-__global__ void k_bc_pass(A4 d, B3 r, int mode, int si, int sj, double val, A4 msk)
+struct BcDesc {
+    double *d; const double *msk;            // component base of the destination; mask (k = 0 slab) or null
+    unsigned sy, sz, msy;                    // strides of destination and mask
+    int lo0, lo1, lo2, mlo0, mlo1;           // array origins
+    int r0, r1, r2, nx, ny, nk;              // region
+    int mode, si, sj; double val;
+};
+#define BC_BATCH 16
+struct BcBatch { int n; BcDesc q[BC_BATCH]; };
+// dest(i,j,k) = val*msk | dest(si,j,k)*msk | dest(i,sj,k)*msk | 0.5*(dest(i,sj,k)+dest(si,j,k));  msk == null: no mask factor
+__global__ void k_bc_pass(BcBatch b)
 {
-    const long nx = r.hi0 - r.lo0 + 1, ny = r.hi1 - r.lo1 + 1, nk = r.hi2 - r.lo2 + 1;
-    const long total = nx * ny * nk;
+    const BcDesc &q = b.q[blockIdx.y];
+    const long nx = q.nx, ny = q.ny;
+    const long total = nx * ny * q.nk;
     for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
-        const int i = r.lo0 + (int)(g % nx), j = r.lo1 + (int)((g / nx) % ny), k = r.lo2 + (int)(g / (nx * ny));
+        const int i = q.r0 + (int)(g % nx), j = q.r1 + (int)((g / nx) % ny), k = q.r2 + (int)(g / (nx * ny));
+        const unsigned kz = (unsigned)(k - q.lo2) * q.sz;
+        auto at = [&](int ii, int jj) -> double & { return q.d[(unsigned)(ii - q.lo0) + (unsigned)(jj - q.lo1) * q.sy + kz]; };
         double x;
-        if (mode == BCP_CONST) x = val;
-        else if (mode == BCP_COPY_I) x = d(si, j, k);
-        else if (mode == BCP_COPY_J) x = d(i, sj, k);
-        else x = 0.5 * (d(i, sj, k) + d(si, j, k));
-        if (msk.p) x = x * msk(i, j, 0);
-        d(i, j, k) = x;
+        if (q.mode == BCP_CONST) x = q.val;
+        else if (q.mode == BCP_COPY_I) x = at(q.si, j);
+        else if (q.mode == BCP_COPY_J) x = at(i, q.sj);
+        else x = 0.5 * (at(i, q.sj) + at(q.si, j));
+        if (q.msk) x = x * q.msk[(unsigned)(i - q.mlo0) + (unsigned)(j - q.mlo1) * q.msy];
+        at(i, j) = x;
     }
+}
+
+struct BcPending { BcDesc q; rh_box w, ra, rb; int level; long npts; };   // write box, up to two read boxes
+static inline bool bx_hit(const rh_box &a, const rh_box &b) { return bx_ok(a) && bx_ok(b) && bx_ok(bx_and(a, b)); }
+
+void *bc_queue_new() { return new std::vector<BcPending>(); }
+void bc_queue_delete(void *q) { delete (std::vector<BcPending> *)q; }
+
+int bc_flush(rh_ctx *c)
+{
+    std::vector<BcPending> &Q = *(std::vector<BcPending> *)c->bcq;
+    if (Q.empty()) return 0;
+    int maxl = 0; for (const BcPending &p : Q) maxl = std::max(maxl, p.level);
+    for (int l = 0; l <= maxl; l++) {
+        BcBatch b; b.n = 0; long big = 0;
+        auto go = [&]() -> int {
+            if (!b.n) return 0;
+            long nb = (big + 255) / 256; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+            k_bc_pass<<<dim3((unsigned)nb, (unsigned)b.n, 1), 256, 0, c->stream>>>(b);
+            b.n = 0; big = 0;
+            RH_LAUNCH_CHECK(); return 0;
+        };
+        for (const BcPending &p : Q) if (p.level == l) { b.q[b.n++] = p.q; big = std::max(big, p.npts); if (b.n == BC_BATCH) RH_TRY(go()); }
+        RH_TRY(go());
+    }
+    Q.clear();
+    return 0;
+}
+// defer passes until the matching bc_end (nesting allowed); only pure ghost-fill sequences may sit inside such a scope
+void bc_begin(rh_ctx *c) { c->bc_defer++; }
+int  bc_end(rh_ctx *c) { if (--c->bc_defer <= 0) { c->bc_defer = 0; return bc_flush(c); } return 0; }
+// queued passes on [p, p + n) must land before anything else touches that memory
+static int bc_flush_if_pending(rh_ctx *c, const double *p, long n)
+{
+    std::vector<BcPending> &Q = *(std::vector<BcPending> *)c->bcq;
+    for (const BcPending &q : Q) if (q.q.d >= p && q.q.d < p + n) return bc_flush(c);
+    return 0;
 }
 
 static int bc_pass(rh_ctx *c, const rh_array4 &dest, int comp, rh_box r, int mode, int si, int sj, double val, const rh_array4 *msk)
@@ -150,19 +205,32 @@ static int bc_pass(rh_ctx *c, const rh_array4 &dest, int comp, rh_box r, int mod
     r = bx_and(r, bx_of(dest));
     if (!bx_ok(r)) return 0;
     A4 d = mkA(dest, comp);
+    if (a4_size(dest) >= (1L << 32)) return rh_fail("bc_pass: array too large for 32-bit indexing");
     // every source index must lie inside the array
     if ((mode == BCP_COPY_I || mode == BCP_CORNER) && (si < dest.lo[0] || si > dest.hi[0])) return rh_fail("bc_pass: source i outside array");
     if ((mode == BCP_COPY_J || mode == BCP_CORNER) && (sj < dest.lo[1] || sj > dest.hi[1])) return rh_fail("bc_pass: source j outside array");
-    A4 m; memset(&m, 0, sizeof m);
+    BcPending p; memset(&p, 0, sizeof p);
+    p.q.d = d.p; p.q.sy = d.sy; p.q.sz = d.sz; p.q.lo0 = d.lo0; p.q.lo1 = d.lo1; p.q.lo2 = d.lo2;
     if (msk) {
         rh_box r2 = bx_slab(r, 2, 0);
         if (!bx_contains(bx_of(*msk), r2)) return rh_fail("bc_pass: mask does not cover the region");
-        m = mkA(*msk);
+        p.q.msk = msk->p; p.q.msy = (unsigned)(msk->hi[0] - msk->lo[0] + 1); p.q.mlo0 = msk->lo[0]; p.q.mlo1 = msk->lo[1];
     }
-    const long total = bx_npts(r);
-    long nb = (total + 255) / 256; if (nb > 2048) nb = 2048;
-    k_bc_pass<<<(int)nb, 256, 0, c->stream>>>(d, mkB(r), mode, si, sj, val, m);
-    RH_LAUNCH_CHECK();
+    p.q.r0 = r.lo[0]; p.q.r1 = r.lo[1]; p.q.r2 = r.lo[2]; p.q.nx = r.hi[0] - r.lo[0] + 1; p.q.ny = r.hi[1] - r.lo[1] + 1; p.q.nk = r.hi[2] - r.lo[2] + 1;
+    p.q.mode = mode; p.q.si = si; p.q.sj = sj; p.q.val = val;
+    p.w = r; p.npts = bx_npts(r);
+    const rh_box none = bx_make(0, 0, 0, -1, -1, -1);
+    p.ra = none; p.rb = none;
+    if (mode == BCP_COPY_I || mode == BCP_CORNER) { p.ra = r; p.ra.lo[0] = p.ra.hi[0] = si; }
+    if (mode == BCP_COPY_J || mode == BCP_CORNER) { p.rb = r; p.rb.lo[1] = p.rb.hi[1] = sj; }
+    std::vector<BcPending> &Q = *(std::vector<BcPending> *)c->bcq;
+    p.level = 0;
+    for (const BcPending &o : Q) {
+        if (o.q.d != p.q.d) continue;
+        if (bx_hit(o.w, p.ra) || bx_hit(o.w, p.rb) || bx_hit(o.w, p.w) || bx_hit(o.ra, p.w) || bx_hit(o.rb, p.w)) p.level = std::max(p.level, o.level + 1);
+    }
+    Q.push_back(p);
+    if (c->bc_defer <= 0) return bc_flush(c);
     return 0;
 }
 
@@ -329,7 +397,7 @@ static int impose_zvel(rh_ctx *c, const MFV &m, int comp, int bccomp)
 }
 
 // REMORA_PhysBCFunct.cpp:21-93
-int halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill)
+static int physbc_impl(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill)
 {
     rh_box gdom = c->dom;
     for (int d = 0; d < 3; d++) if (m.ix[d]) gdom.hi[d] += 1;
@@ -344,6 +412,13 @@ int halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int nc
     if (m.ix[0]) return impose_xvel(c, m, msk, icomp, bccomp);
     if (m.ix[1]) return impose_yvel(c, m, msk, icomp, bccomp);
     return impose_zvel(c, m, icomp, bccomp);
+}
+
+int halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill)
+{
+    BcScope bcs(c);                                       // all components' passes of one call share the launches
+    RH_TRY(physbc_impl(c, m, msk, icomp, ncomp, bccomp, n_not_fill));
+    return bcs.end();
 }
 
 // REMORA::FillPatch at level 0 (BoundaryConditions/REMORA_FillPatch.cpp:96-125) == FillBoundary + physbc

@@ -430,10 +430,11 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
         RH_LAUNCH_CHECK();
     }
     // ---- ghost cells of the new time level, :735-755
+    BcScope bcs(c);
     RH_TRY(halo_fillpatch(c, mfv(c, s->ubar, 1, 0, 0), s->msku, RH_BCV_UBAR, knew, 1));
     RH_TRY(halo_fillpatch(c, mfv(c, s->vbar, 0, 1, 0), s->mskv, RH_BCV_VBAR, knew, 1));
     RH_TRY(halo_fillpatch(c, mfv(c, s->zeta, 0, 0, 0), s->mskr, RH_BCV_ZETA, knew, 1));
-    return 0;
+    return bcs.end();
 }
 
 // REMORA::advance_2d_onestep, REMORA_advance_2d_onestep.cpp:6-53
