@@ -293,6 +293,167 @@ extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Fused velocity corrector for u (IO = 1) or v (JO = 1): the Adams-Bashforth update (REMORA_advance_3d.cpp:104-123), the
+// implicit vertical viscosity (vert_visc_3d.cpp:10-107) and the depth-mean replacement (vert_mean_3d.cpp:10-47) in one column
+// kernel, same mapping as k_vert_visc_lds.  The three leaves run on the same box with no ghost fill between them
+// (advance_3d.cpp:104-150), and each column only needs itself and its (i-1 | j-1) neighbour, so the velocity travels
+// HBM -> registers -> LDS -> HBM once instead of three round trips.  Arithmetic per expression is that of the three leaves:
+//   forward sweep  : phi(k) = (u + c2 ru) * (2 / (Hz' + Hz)) on the fly, elimination coefficients CF, DC -> LDS
+//   backward sweep : phi(k) recomputed from the same operands (re-read through L2 / Infinity Cache), back-substitution, and
+//                    the updated phi(k) and Hzk(k) parked in the LDS slots of DC(k), CF(k), which are dead by then
+//   mean           : ascending sums over LDS in the reference's order, then the only store of the velocity.
+template <int IO, int JO>
+__global__ void __launch_bounds__(64)
+k_uv_corrector(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm, A4 pn, A4 msk, int N, double dt, double cab)
+{
+    extern __shared__ double vv_lds[];
+    const int lane = threadIdx.x;
+    double *sCF = vv_lds + lane, *sDC = vv_lds + (size_t)(N + 2) * 64 + lane;      // s[k * 64]
+    const int i = bx.lo0 + (int)blockIdx.x * 64 + lane, j = bx.lo1 + (int)blockIdx.y;
+    const bool act = i <= bx.hi0;
+    const int ic = act ? i : bx.hi0;
+    const int ii = ic - IO, jj = j - JO;
+    const bool edge = (IO == 1) && (lane == 0);
+    const double sixth = 1.0 / 6.0, third = 1.0 / 3.0;
+    auto second = [&](double own, double extra) -> double {
+        if (IO == 1) { const double s = __shfl_up(own, 1); return edge ? extra : s; }
+        return extra;
+    };
+    auto ld2 = [&](const A4 &a, int k) -> double {
+        if (IO == 1) return edge ? a(ic - 1, j, k) : 0.0;
+        return a(ic, jj, k);
+    };
+    // k-invariant factor of the Adams-Bashforth term: cff * (pm + pm') * (pn + pn'), advance_3d.cpp:113-121
+    const double c2 = cab * (pm(ic, j, 0) + pm(ii, jj, 0)) * (pn(ic, j, 0) + pn(ii, jj, 0));
+    auto ab3 = [&](double u, double r, double hsum) -> double { double x = u; x += c2 * r; x *= 2.0 / hsum; return x; };
+    // ---- upward elimination
+    double Hzk_m, AK_m, AK_0, phi_m;
+    {
+        const double h = Hz(ic, j, 0), hx = ld2(Hz, 0), a0 = Akv(ic, j, 0), a0x = ld2(Akv, 0), a1 = Akv(ic, j, 1), a1x = ld2(Akv, 1);
+        const double hs = second(h, hx) + h;
+        Hzk_m = 0.5 * hs;
+        AK_m = 0.5 * (second(a0, a0x) + a0);
+        AK_0 = 0.5 * (second(a1, a1x) + a1);
+        phi_m = ab3(phi(ic, j, 0), rphi(ic, j, 0), hs);
+    }
+    double CFp = 0.0, DCp = 0.0;
+    double nP[VV_U], nR[VV_U], nH[VV_U], nHx[VV_U], nA[VV_U], nAx[VV_U];
+#pragma unroll
+    for (int u = 0; u < VV_U; u++) {
+        const int k = 1 + u; const bool ok = k <= N;
+        nP[u] = ok ? phi(ic, j, k) : 0.0; nR[u] = ok ? rphi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
+        nA[u] = ok ? Akv(ic, j, k + 1) : 0.0; nAx[u] = ok ? ld2(Akv, k + 1) : 0.0;
+    }
+    for (int kb = 1; kb <= N; kb += VV_U) {
+        double cP[VV_U], cR[VV_U], cH[VV_U], cHx[VV_U], cA[VV_U], cAx[VV_U];
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) { cP[u] = nP[u]; cR[u] = nR[u]; cH[u] = nH[u]; cHx[u] = nHx[u]; cA[u] = nA[u]; cAx[u] = nAx[u]; }
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) {
+            const int k = kb + VV_U + u; const bool ok = k <= N;
+            nP[u] = ok ? phi(ic, j, k) : 0.0; nR[u] = ok ? rphi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
+            nA[u] = ok ? Akv(ic, j, k + 1) : 0.0; nAx[u] = ok ? ld2(Akv, k + 1) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) {
+            const int k = kb + u;
+            const double hs = second(cH[u], cHx[u]) + cH[u];
+            const double Hzk_0 = 0.5 * hs;
+            const double AK_p = 0.5 * (second(cA[u], cAx[u]) + cA[u]);
+            if (k <= N) {
+                const double phi_0 = ab3(cP[u], cR[u], hs);
+                const double oHzkm1 = 1.0 / Hzk_m;
+                const double oHz = 1.0 / Hzk_0;
+                const double FC = sixth * Hzk_m - dt * AK_m / Hzk_m;
+                double CF = sixth * Hzk_0 - dt * AK_p / Hzk_0;
+                const double BC = third * (Hzk_m + Hzk_0) + dt * AK_0 * (oHzkm1 + oHz);
+                const double cff = 1.0 / (BC - FC * CFp);
+                CF *= cff;
+                const double DC = cff * (phi_0 - phi_m - FC * DCp);
+                sCF[k * 64] = CF; sDC[k * 64] = DC;
+                CFp = CF; DCp = DC; Hzk_m = Hzk_0; AK_m = AK_0; AK_0 = AK_p; phi_m = phi_0;
+            }
+        }
+    }
+    // ---- back-substitution fused with the viscosity update; results stay in LDS.  Here AK_0 = AK(N+1).
+    double DC_up = 0.0, DCs_up = DC_up * AK_0;
+#pragma unroll
+    for (int u = 0; u < VV_U; u++) {
+        const int k = N - u; const bool ok = k >= 0;
+        nP[u] = ok ? phi(ic, j, k) : 0.0; nR[u] = ok ? rphi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
+        nA[u] = ok ? Akv(ic, j, k) : 0.0; nAx[u] = ok ? ld2(Akv, k) : 0.0;
+    }
+    for (int kb = N; kb >= 0; kb -= VV_U) {
+        double cP[VV_U], cR[VV_U], cH[VV_U], cHx[VV_U], cA[VV_U], cAx[VV_U];
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) { cP[u] = nP[u]; cR[u] = nR[u]; cH[u] = nH[u]; cHx[u] = nHx[u]; cA[u] = nA[u]; cAx[u] = nAx[u]; }
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) {
+            const int k = kb - VV_U - u; const bool ok = k >= 0;
+            nP[u] = ok ? phi(ic, j, k) : 0.0; nR[u] = ok ? rphi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
+            nA[u] = ok ? Akv(ic, j, k) : 0.0; nAx[u] = ok ? ld2(Akv, k) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < VV_U; u++) {
+            const int k = kb - u;
+            const double hs = second(cH[u], cHx[u]) + cH[u];
+            const double Hzk = 0.5 * hs;
+            const double AKk = 0.5 * (second(cA[u], cAx[u]) + cA[u]);
+            if (k >= 0) {
+                double DC;
+                if (k >= 1) { DC = sDC[k * 64]; DC -= sCF[k * 64] * DC_up; }
+                else DC = 0.0;
+                const double DCs = DC * AKk;
+                const double oHz = 1.0 / Hzk;
+                const double cff = dt * oHz * (DCs_up - DCs);
+                sDC[k * 64] = ab3(cP[u], cR[u], hs) + cff;           // phi after vert_visc_3d
+                sCF[k * 64] = Hzk;
+                DC_up = DC; DCs_up = DCs;
+            }
+        }
+    }
+    // ---- vert_mean_3d: ascending sums in the reference's order (:22-34), then the correction (:36-46)
+    double CF = sCF[0], DCm = sDC[0] * CF;
+    for (int k = 1; k <= N; k++) { const double Hzf = sCF[k * 64]; CF += Hzf; DCm += sDC[k * 64] * Hzf; }
+    const double on = 2.0 / (dxlen(ii, jj, 0) + dxlen(ic, j, 0));
+    const double cff1 = 1.0 / (CF * (on));
+    DCm = (DCm * (on) - Davg1(ic, j, 0)) * cff1;
+    const double m = msk(ic, j, 0);
+    if (act)
+        for (int k = 0; k <= N; k++) { double x = sDC[k * 64]; x -= DCm; x *= m; phi(i, j, k) = x; }
+}
+
+// AB3 + vert_visc_3d + vert_mean_3d for u and v; *applied = 0 when the fused form does not apply (the caller runs the leaves)
+int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
+{
+    const int N = c->N; const double dt = c->prm.dt;
+    const size_t lds_bytes = sizeof(double) * 2 * (size_t)(N + 2) * 64;
+    *applied = 0;
+    if (c->unfused || lds_bytes > 64 * 1024) return 0;
+    TScope t(c, "uv_corrector");
+    const int iic = istep, ntfirst = 0;
+    double cab;
+    if (iic == ntfirst) cab = 0.25 * dt; else if (iic == ntfirst + 1) cab = 0.25 * dt * 3.0 / 2.0; else cab = 0.25 * dt * 23.0 / 12.0;
+    rh_box xbx = bx_nodal(c->bx, 0), ybx = bx_nodal(c->bx, 1);
+    xbx.lo[2] = ybx.lo[2] = 0; xbx.hi[2] = ybx.hi[2] = N;
+    rh_box xw = xbx, yw = ybx; xw.hi[2] = yw.hi[2] = N + 1;
+    const rh_box xs = bx_growlo_i(xbx), ys = bx_growlo_j(ybx), xsw = bx_growlo_i(xw), ysw = bx_growlo_j(yw);
+    RH_NEED(s->xvel_new, xbx); RH_NEED(s->yvel_new, ybx); RH_NEED(s->ru, xbx); RH_NEED(s->rv, ybx);
+    RH_NEED(s->Hz, xs); RH_NEED(s->Hz, ys); RH_NEED(s->Akv, xsw); RH_NEED(s->Akv, ysw);
+    RH_NEED(s->pm, bx_slab(xs, 2, 0)); RH_NEED(s->pn, bx_slab(xs, 2, 0)); RH_NEED(s->pm, bx_slab(ys, 2, 0)); RH_NEED(s->pn, bx_slab(ys, 2, 0));
+    RH_NEED(s->DU_avg1, bx_slab(xbx, 2, 0)); RH_NEED(s->DV_avg1, bx_slab(ybx, 2, 0)); RH_NEED(s->msku, bx_slab(xbx, 2, 0)); RH_NEED(s->mskv, bx_slab(ybx, 2, 0));
+    const dim3 gx((xbx.hi[0] - xbx.lo[0] + 64) / 64, xbx.hi[1] - xbx.lo[1] + 1, 1), gy((ybx.hi[0] - ybx.lo[0] + 64) / 64, ybx.hi[1] - ybx.lo[1] + 1, 1);
+    k_uv_corrector<1, 0><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn),
+        mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab);
+    RH_LAUNCH_CHECK();
+    k_uv_corrector<0, 1><<<gy, 64, lds_bytes, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm),
+        mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab);
+    RH_LAUNCH_CHECK();
+    *applied = 1;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // REMORA::vert_mean_3d, REMORA_vert_mean_3d.cpp:10-47: replace the depth mean of u (v) by the barotropic DU_avg1 (DV_avg1)
 __global__ void k_vert_mean(B3 bx, int ioff, int joff, A4 phi, A4 Hz, A4 Davg1, A4 dxlen, A4 msk, int N)
 {

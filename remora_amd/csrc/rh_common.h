@@ -138,6 +138,7 @@ int  launch_massflux_old(rh_ctx *c, rh_state *s);
 int  launch_vmix(rh_ctx *c, rh_state *s);
 int  launch_set_zeta(rh_ctx *c, rh_state *s);
 int  launch_uv_ab3(rh_ctx *c, rh_state *s, int istep);
+int  launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied);   // fused: AB3 + vert_visc_3d + vert_mean_3d for u, v
 int  launch_mask_cons(rh_ctx *c, rh_state *s);
 int  launch_prestep_t3(rh_ctx *c, rh_state *s, int iic, int ntfirst);   // fused: 3 tracers x (prestep_t + t3dmix)
 int  launch_rhs_t3(rh_ctx *c, rh_state *s);                             // fused: 3 tracers x rhs_t_3d

@@ -123,11 +123,15 @@ static int advance_3d(rh_ctx *c, rh_state *s, int istep)
     const rh_box bx = c->bx, xbx = bx_nodal(bx, 0), ybx = bx_nodal(bx, 1);
     const rh_box gbx2 = bx_grow(bx, 2, 2, 0), gbx1 = bx_grow(bx, 1, 1, 0);
     RH_TRY(rh_stretch_transform(c, s));                                                            // :40
-    RH_TRY(launch_uv_ab3(c, s, istep));                                                            // :104-123
-    RH_TRY(rh_vert_visc_3d(c, xbx, 1, 0, s->xvel_new, s->Hz, s->Akv, N, dt));                      // :132
-    RH_TRY(rh_vert_visc_3d(c, ybx, 0, 1, s->yvel_new, s->Hz, s->Akv, N, dt));                      // :138
-    RH_TRY(rh_vert_mean_3d(c, xbx, 1, 0, s->xvel_new, s->Hz, s->DU_avg1, s->pn, s->msku, N));      // :144
-    RH_TRY(rh_vert_mean_3d(c, ybx, 0, 1, s->yvel_new, s->Hz, s->DV_avg1, s->pm, s->mskv, N));      // :150
+    int fused_uv = 0;
+    RH_TRY(launch_uv_corrector(c, s, istep, &fused_uv));                                           // :104-150 in one column kernel per velocity
+    if (!fused_uv) {
+        RH_TRY(launch_uv_ab3(c, s, istep));                                                        // :104-123
+        RH_TRY(rh_vert_visc_3d(c, xbx, 1, 0, s->xvel_new, s->Hz, s->Akv, N, dt));                  // :132
+        RH_TRY(rh_vert_visc_3d(c, ybx, 0, 1, s->yvel_new, s->Hz, s->Akv, N, dt));                  // :138
+        RH_TRY(rh_vert_mean_3d(c, xbx, 1, 0, s->xvel_new, s->Hz, s->DU_avg1, s->pn, s->msku, N));  // :144
+        RH_TRY(rh_vert_mean_3d(c, ybx, 0, 1, s->yvel_new, s->Hz, s->DV_avg1, s->pm, s->mskv, N));  // :150
+    }
     {
         TScope t(c, "halo");
         BcScope bcs(c);
