@@ -158,15 +158,24 @@ __global__ void k_vert_visc(B3 bx, int ioff, int joff, A4 phi, A4 Hz, A4 Akv, A4
         DC_up = DC; DCs_up = DCs;
     }
 }
-// ---- vert_visc_3d with the tridiagonal coefficients in LDS.  One wavefront per block, one column per lane; CF(k), DC(k) of
-// the elimination live in LDS ([k][lane], conflict-free) instead of a global work-space slab, which removes 4 of the 11
-// doubles per cell the slab form moves.  The column-neighbour (i-1) of a u column comes from the neighbouring lane by a
-// cross-lane shuffle (only lane 0 loads it).  Loads are independent of the recurrence, so they are issued VV_U levels ahead
-// of their use (explicit double-buffered batches): with ~3 wavefronts per CU (LDS-limited) that is what hides HBM latency.
-#define VV_U 8
-template <int IO, int JO>
-__global__ void __launch_bounds__(64)
-k_vert_visc_lds(B3 bx, A4 phi, A4 Hz, A4 Akv, int N, double dt)
+// ---- column solver with the tridiagonal coefficients in LDS: vert_visc_3d alone (FULL = 0) or the whole velocity corrector
+// (FULL = 1: Adams-Bashforth update, REMORA_advance_3d.cpp:104-123 + vert_visc_3d.cpp:10-107 + vert_mean_3d.cpp:10-47; the three
+// leaves run on the same box with no ghost fill between them and each column only needs itself and its (i-1 | j-1) neighbour,
+// so the velocity travels HBM -> registers -> LDS -> HBM once instead of three round trips).
+// One wavefront per block, one column per lane.  CF(k), DC(k) of the elimination live in LDS ([k][lane], conflict-free)
+// instead of the reference's six scratch arrays.  The (i-1) neighbour of a u column comes from the neighbouring lane by a
+// cross-lane shuffle (only lane 0 loads it).  LDS limits a CU to ~3 such wavefronts, so HBM latency is hidden inside the wave:
+// the operands of level k+D are requested while level k is eliminated (a register ring of D levels, statically indexed; the
+// vector-memory counter lets the wave wait for the oldest level only).  D x loads-per-level stays below the 63 outstanding loads
+// the counter can track.  Levels past the end are clamped, not branched around, so the ring is branch-free.
+//   forward sweep  : [FULL: phi(k) = (u + c2 ru) * (2 / (Hz' + Hz)) on the fly] elimination coefficients CF, DC -> LDS
+//   backward sweep : back-substitution fused with the update; FULL: phi(k) recomputed from the same operands (re-read through
+//                    L2 / Infinity Cache) and the updated phi(k), Hzk(k) parked in the LDS slots of DC(k), CF(k), dead by then
+//   FULL mean      : ascending sums over LDS in the reference's order, then the only store of the velocity.
+struct ColLvl { double P, R, H, Hx, A, Ax; };
+template <int IO, int JO, int FULL, int D>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))     // LDS caps occupancy anyway: give the ring all the registers it wants
+k_column_solver(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm, A4 pn, A4 msk, int N, double dt, double cab)
 {
     extern __shared__ double vv_lds[];
     const int lane = threadIdx.x;
@@ -174,7 +183,7 @@ k_vert_visc_lds(B3 bx, A4 phi, A4 Hz, A4 Akv, int N, double dt)
     const int i = bx.lo0 + (int)blockIdx.x * 64 + lane, j = bx.lo1 + (int)blockIdx.y;
     const bool act = i <= bx.hi0;
     const int ic = act ? i : bx.hi0;                       // inactive lanes shadow the last column (no stores)
-    const int jj = j - JO;
+    const int ii = ic - IO, jj = j - JO;
     const bool edge = (IO == 1) && (lane == 0);            // the only lane whose i-1 neighbour is not in the wave
     const double sixth = 1.0 / 6.0, third = 1.0 / 3.0;
     // second point of the face average: (i-1,j) via shuffle, (i,j-1) via its own load, or the same point (tracers)
@@ -188,89 +197,110 @@ k_vert_visc_lds(B3 bx, A4 phi, A4 Hz, A4 Akv, int N, double dt)
         if (JO == 1) return a(ic, jj, k);
         return 0.0;
     };
-    // ---- upward elimination, :51-75
+    // k-invariant factor of the Adams-Bashforth term: cff * (pm + pm') * (pn + pn'), advance_3d.cpp:113-121
+    double c2 = 0.0;
+    if (FULL) c2 = cab * (pm(ic, j, 0) + pm(ii, jj, 0)) * (pn(ic, j, 0) + pn(ii, jj, 0));
+    auto start = [&](double u, double r, double hsum) -> double {     // the field the solve starts from
+        if (!FULL) return u;
+        double x = u; x += c2 * r; x *= 2.0 / hsum; return x;
+    };
+    auto load_f = [&](int k) -> ColLvl {                 // forward operands of level k: phi, Hz at k, Akv at k+1
+        const int kc = k < N ? k : N;
+        ColLvl v; v.P = phi(ic, j, kc); v.R = FULL ? rphi(ic, j, kc) : 0.0; v.H = Hz(ic, j, kc); v.Hx = ld2(Hz, kc);
+        v.A = Akv(ic, j, kc + 1); v.Ax = ld2(Akv, kc + 1); return v;
+    };
+    auto load_b = [&](int k) -> ColLvl {                 // backward operands of level k
+        const int kc = k > 0 ? k : 0;
+        ColLvl v; v.P = phi(ic, j, kc); v.R = FULL ? rphi(ic, j, kc) : 0.0; v.H = Hz(ic, j, kc); v.Hx = ld2(Hz, kc);
+        v.A = Akv(ic, j, kc); v.Ax = ld2(Akv, kc); return v;
+    };
+    // ---- upward elimination, vert_visc_3d.cpp:51-75
     double Hzk_m, AK_m, AK_0, phi_m;
     {
         const double h = Hz(ic, j, 0), hx = ld2(Hz, 0), a0 = Akv(ic, j, 0), a0x = ld2(Akv, 0), a1 = Akv(ic, j, 1), a1x = ld2(Akv, 1);
-        Hzk_m = 0.5 * (second(h, hx) + h);
+        const double hs = second(h, hx) + h;
+        Hzk_m = 0.5 * hs;
         AK_m = 0.5 * (second(a0, a0x) + a0);
         AK_0 = 0.5 * (second(a1, a1x) + a1);
-        phi_m = phi(ic, j, 0);
+        phi_m = start(phi(ic, j, 0), FULL ? rphi(ic, j, 0) : 0.0, hs);
     }
     double CFp = 0.0, DCp = 0.0;
-    double nP[VV_U], nH[VV_U], nHx[VV_U], nA[VV_U], nAx[VV_U];
+    auto fwd = [&](int k, const ColLvl &c) {              // level k of the elimination (all lanes: `second` shuffles)
+        const double hs = second(c.H, c.Hx) + c.H;
+        const double Hzk_0 = 0.5 * hs;
+        const double AK_p = 0.5 * (second(c.A, c.Ax) + c.A);
+        const double phi_0 = start(c.P, c.R, hs);
+        const double oHzkm1 = 1.0 / Hzk_m;
+        const double oHz = 1.0 / Hzk_0;
+        const double FC = sixth * Hzk_m - dt * AK_m / Hzk_m;
+        double CF = sixth * Hzk_0 - dt * AK_p / Hzk_0;
+        const double BC = third * (Hzk_m + Hzk_0) + dt * AK_0 * (oHzkm1 + oHz);
+        const double cff = 1.0 / (BC - FC * CFp);
+        CF *= cff;
+        const double DC = cff * (phi_0 - phi_m - FC * DCp);
+        sCF[k * 64] = CF; sDC[k * 64] = DC;
+        // without the AB3 term phi_0 IS the loaded register: carried into the next level as phi_m it would outlive the ring slot,
+        // and the copies that keeps alive make every loop iteration start by draining the ring.  An opaque move cuts the tie.
+        double carry = phi_0; asm volatile("" : "+v"(carry));
+        CFp = CF; DCp = DC; Hzk_m = Hzk_0; AK_m = AK_0; AK_0 = AK_p; phi_m = carry;
+    };
+    ColLvl ring[D];
 #pragma unroll
-    for (int u = 0; u < VV_U; u++) {
-        const int k = 1 + u; const bool ok = k <= N;
-        nP[u] = ok ? phi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
-        nA[u] = ok ? Akv(ic, j, k + 1) : 0.0; nAx[u] = ok ? ld2(Akv, k + 1) : 0.0;
-    }
-    for (int kb = 1; kb <= N; kb += VV_U) {
-        double cP[VV_U], cH[VV_U], cHx[VV_U], cA[VV_U], cAx[VV_U];
+    for (int u = 0; u < D; u++) ring[u] = load_f(1 + u);
+    int kb = 1;
+    for (; kb + D - 1 <= N; kb += D) {                    // full batches: straight-line code, one level's loads per level of work
 #pragma unroll
-        for (int u = 0; u < VV_U; u++) { cP[u] = nP[u]; cH[u] = nH[u]; cHx[u] = nHx[u]; cA[u] = nA[u]; cAx[u] = nAx[u]; }
-#pragma unroll
-        for (int u = 0; u < VV_U; u++) {                 // next batch in flight while this one is eliminated
-            const int k = kb + VV_U + u; const bool ok = k <= N;
-            nP[u] = ok ? phi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
-            nA[u] = ok ? Akv(ic, j, k + 1) : 0.0; nAx[u] = ok ? ld2(Akv, k + 1) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < VV_U; u++) {
-            const int k = kb + u;
-            const double Hzk_0 = 0.5 * (second(cH[u], cHx[u]) + cH[u]);
-            const double AK_p = 0.5 * (second(cA[u], cAx[u]) + cA[u]);
-            if (k <= N) {
-                const double phi_0 = cP[u];
-                const double oHzkm1 = 1.0 / Hzk_m;
-                const double oHz = 1.0 / Hzk_0;
-                const double FC = sixth * Hzk_m - dt * AK_m / Hzk_m;
-                double CF = sixth * Hzk_0 - dt * AK_p / Hzk_0;
-                const double BC = third * (Hzk_m + Hzk_0) + dt * AK_0 * (oHzkm1 + oHz);
-                const double cff = 1.0 / (BC - FC * CFp);
-                CF *= cff;
-                const double DC = cff * (phi_0 - phi_m - FC * DCp);
-                sCF[k * 64] = CF; sDC[k * 64] = DC;
-                CFp = CF; DCp = DC; Hzk_m = Hzk_0; AK_m = AK_0; AK_0 = AK_p; phi_m = phi_0;
-            }
+        for (int u = 0; u < D; u++) {
+            fwd(kb + u, ring[u]);
+            __builtin_amdgcn_sched_barrier(0);             // keep the request for level k+D next to the work of level k
+            ring[u] = load_f(kb + u + D);                  // into the registers level k has just released
         }
     }
+#pragma unroll
+    for (int u = 0; u < D; u++) if (kb + u <= N) fwd(kb + u, ring[u]);      // tail: operands are already in the ring
     // ---- back-substitution fused with the update, :81-106.  Here AK_0 = AK(N+1).
     double DC_up = 0.0, DCs_up = DC_up * AK_0;
+    auto bwd = [&](int k, const ColLvl &c) {
+        const double hs = second(c.H, c.Hx) + c.H;
+        const double Hzk = 0.5 * hs;
+        const double AKk = 0.5 * (second(c.A, c.Ax) + c.A);
+        double DC;
+        if (k >= 1) { DC = sDC[k * 64]; DC -= sCF[k * 64] * DC_up; }
+        else DC = 0.0;
+        const double DCs = DC * AKk;
+        const double oHz = 1.0 / Hzk;
+        const double cff = dt * oHz * (DCs_up - DCs);
+        const double x = start(c.P, c.R, hs) + cff;              // phi after vert_visc_3d
+        if (FULL) { sDC[k * 64] = x; sCF[k * 64] = Hzk; }
+        else if (act) phi(i, j, k) = x;
+        DC_up = DC; DCs_up = DCs;
+    };
 #pragma unroll
-    for (int u = 0; u < VV_U; u++) {
-        const int k = N - u; const bool ok = k >= 0;
-        nP[u] = ok ? phi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
-        nA[u] = ok ? Akv(ic, j, k) : 0.0; nAx[u] = ok ? ld2(Akv, k) : 0.0;
-    }
-    for (int kb = N; kb >= 0; kb -= VV_U) {
-        double cP[VV_U], cH[VV_U], cHx[VV_U], cA[VV_U], cAx[VV_U];
+    for (int u = 0; u < D; u++) ring[u] = load_b(N - u);
+    kb = N;
+    for (; kb - D + 1 >= 1; kb -= D) {                    // full batches of levels >= 1
 #pragma unroll
-        for (int u = 0; u < VV_U; u++) { cP[u] = nP[u]; cH[u] = nH[u]; cHx[u] = nHx[u]; cA[u] = nA[u]; cAx[u] = nAx[u]; }
-#pragma unroll
-        for (int u = 0; u < VV_U; u++) {
-            const int k = kb - VV_U - u; const bool ok = k >= 0;
-            nP[u] = ok ? phi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
-            nA[u] = ok ? Akv(ic, j, k) : 0.0; nAx[u] = ok ? ld2(Akv, k) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < VV_U; u++) {
-            const int k = kb - u;
-            const double Hzk = 0.5 * (second(cH[u], cHx[u]) + cH[u]);
-            const double AKk = 0.5 * (second(cA[u], cAx[u]) + cA[u]);
-            if (k >= 0) {
-                double DC;
-                if (k >= 1) { DC = sDC[k * 64]; DC -= sCF[k * 64] * DC_up; }
-                else DC = 0.0;
-                const double DCs = DC * AKk;
-                const double oHz = 1.0 / Hzk;
-                const double cff = dt * oHz * (DCs_up - DCs);
-                if (act) phi(i, j, k) = cP[u] + cff;
-                DC_up = DC; DCs_up = DCs;
-            }
+        for (int u = 0; u < D; u++) {
+            bwd(kb - u, ring[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            ring[u] = load_b(kb - u - D);
         }
     }
+#pragma unroll
+    for (int u = 0; u < D; u++) if (kb - u >= 0) bwd(kb - u, ring[u]);
+    if (!FULL) return;
+    // ---- vert_mean_3d: ascending sums in the reference's order (:22-34), then the correction (:36-46)
+    double CF = sCF[0], DCm = sDC[0] * CF;
+    for (int k = 1; k <= N; k++) { const double Hzf = sCF[k * 64]; CF += Hzf; DCm += sDC[k * 64] * Hzf; }
+    const double on = 2.0 / (dxlen(ii, jj, 0) + dxlen(ic, j, 0));
+    const double cff1 = 1.0 / (CF * (on));
+    DCm = (DCm * (on) - Davg1(ic, j, 0)) * cff1;
+    const double m = msk(ic, j, 0);
+    if (act)
+        for (int k = 0; k <= N; k++) { double x = sDC[k * 64]; x -= DCm; x *= m; phi(i, j, k) = x; }
 }
+#define VV_D_T 16      // ring depth, tracers (3 loads per level)
+#define VV_D_V 10      // ring depth, velocities (5-6 loads per level)
 
 extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 phi, rh_array4 Hz, rh_array4 Akv, int N, double dt)
 {
@@ -284,145 +314,16 @@ extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_
     const size_t lds_bytes = sizeof(double) * 2 * (size_t)(N + 2) * 64;
     if (!c->unfused && lds_bytes <= 64 * 1024) {         // coefficients in LDS (up to 62 levels at >= 2 wavefronts per CU)
         const dim3 grid((phi_bx.hi[0] - phi_bx.lo[0] + 64) / 64, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);
-        if (ioff) k_vert_visc_lds<1, 0><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), mkA(Hz), mkA(Akv), N, dt);
-        else if (joff) k_vert_visc_lds<0, 1><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), mkA(Hz), mkA(Akv), N, dt);
-        else k_vert_visc_lds<0, 0><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), mkA(Hz), mkA(Akv), N, dt);
+        const A4 z = mkA(phi);                           // unused operands of the FULL form
+        if (ioff) k_column_solver<1, 0, 0, VV_D_V><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
+        else if (joff) k_column_solver<0, 1, 0, VV_D_V><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
+        else k_column_solver<0, 0, 0, VV_D_T><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
     } else                                               // deeper columns: coefficients in the global work-space slab
         k_vert_visc<<<grid2(phi_bx), rh_block(), 0, c->stream>>>(mkB(phi_bx), ioff, joff, mkA(phi), mkA(Hz), mkA(Akv), mkA(c->wCF), mkA(c->wDC), N, dt);
     RH_LAUNCH_CHECK(); return 0;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Fused velocity corrector for u (IO = 1) or v (JO = 1): the Adams-Bashforth update (REMORA_advance_3d.cpp:104-123), the
-// implicit vertical viscosity (vert_visc_3d.cpp:10-107) and the depth-mean replacement (vert_mean_3d.cpp:10-47) in one column
-// kernel, same mapping as k_vert_visc_lds.  The three leaves run on the same box with no ghost fill between them
-// (advance_3d.cpp:104-150), and each column only needs itself and its (i-1 | j-1) neighbour, so the velocity travels
-// HBM -> registers -> LDS -> HBM once instead of three round trips.  Arithmetic per expression is that of the three leaves:
-//   forward sweep  : phi(k) = (u + c2 ru) * (2 / (Hz' + Hz)) on the fly, elimination coefficients CF, DC -> LDS
-//   backward sweep : phi(k) recomputed from the same operands (re-read through L2 / Infinity Cache), back-substitution, and
-//                    the updated phi(k) and Hzk(k) parked in the LDS slots of DC(k), CF(k), which are dead by then
-//   mean           : ascending sums over LDS in the reference's order, then the only store of the velocity.
-template <int IO, int JO>
-__global__ void __launch_bounds__(64)
-k_uv_corrector(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm, A4 pn, A4 msk, int N, double dt, double cab)
-{
-    extern __shared__ double vv_lds[];
-    const int lane = threadIdx.x;
-    double *sCF = vv_lds + lane, *sDC = vv_lds + (size_t)(N + 2) * 64 + lane;      // s[k * 64]
-    const int i = bx.lo0 + (int)blockIdx.x * 64 + lane, j = bx.lo1 + (int)blockIdx.y;
-    const bool act = i <= bx.hi0;
-    const int ic = act ? i : bx.hi0;
-    const int ii = ic - IO, jj = j - JO;
-    const bool edge = (IO == 1) && (lane == 0);
-    const double sixth = 1.0 / 6.0, third = 1.0 / 3.0;
-    auto second = [&](double own, double extra) -> double {
-        if (IO == 1) { const double s = __shfl_up(own, 1); return edge ? extra : s; }
-        return extra;
-    };
-    auto ld2 = [&](const A4 &a, int k) -> double {
-        if (IO == 1) return edge ? a(ic - 1, j, k) : 0.0;
-        return a(ic, jj, k);
-    };
-    // k-invariant factor of the Adams-Bashforth term: cff * (pm + pm') * (pn + pn'), advance_3d.cpp:113-121
-    const double c2 = cab * (pm(ic, j, 0) + pm(ii, jj, 0)) * (pn(ic, j, 0) + pn(ii, jj, 0));
-    auto ab3 = [&](double u, double r, double hsum) -> double { double x = u; x += c2 * r; x *= 2.0 / hsum; return x; };
-    // ---- upward elimination
-    double Hzk_m, AK_m, AK_0, phi_m;
-    {
-        const double h = Hz(ic, j, 0), hx = ld2(Hz, 0), a0 = Akv(ic, j, 0), a0x = ld2(Akv, 0), a1 = Akv(ic, j, 1), a1x = ld2(Akv, 1);
-        const double hs = second(h, hx) + h;
-        Hzk_m = 0.5 * hs;
-        AK_m = 0.5 * (second(a0, a0x) + a0);
-        AK_0 = 0.5 * (second(a1, a1x) + a1);
-        phi_m = ab3(phi(ic, j, 0), rphi(ic, j, 0), hs);
-    }
-    double CFp = 0.0, DCp = 0.0;
-    double nP[VV_U], nR[VV_U], nH[VV_U], nHx[VV_U], nA[VV_U], nAx[VV_U];
-#pragma unroll
-    for (int u = 0; u < VV_U; u++) {
-        const int k = 1 + u; const bool ok = k <= N;
-        nP[u] = ok ? phi(ic, j, k) : 0.0; nR[u] = ok ? rphi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
-        nA[u] = ok ? Akv(ic, j, k + 1) : 0.0; nAx[u] = ok ? ld2(Akv, k + 1) : 0.0;
-    }
-    for (int kb = 1; kb <= N; kb += VV_U) {
-        double cP[VV_U], cR[VV_U], cH[VV_U], cHx[VV_U], cA[VV_U], cAx[VV_U];
-#pragma unroll
-        for (int u = 0; u < VV_U; u++) { cP[u] = nP[u]; cR[u] = nR[u]; cH[u] = nH[u]; cHx[u] = nHx[u]; cA[u] = nA[u]; cAx[u] = nAx[u]; }
-#pragma unroll
-        for (int u = 0; u < VV_U; u++) {
-            const int k = kb + VV_U + u; const bool ok = k <= N;
-            nP[u] = ok ? phi(ic, j, k) : 0.0; nR[u] = ok ? rphi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
-            nA[u] = ok ? Akv(ic, j, k + 1) : 0.0; nAx[u] = ok ? ld2(Akv, k + 1) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < VV_U; u++) {
-            const int k = kb + u;
-            const double hs = second(cH[u], cHx[u]) + cH[u];
-            const double Hzk_0 = 0.5 * hs;
-            const double AK_p = 0.5 * (second(cA[u], cAx[u]) + cA[u]);
-            if (k <= N) {
-                const double phi_0 = ab3(cP[u], cR[u], hs);
-                const double oHzkm1 = 1.0 / Hzk_m;
-                const double oHz = 1.0 / Hzk_0;
-                const double FC = sixth * Hzk_m - dt * AK_m / Hzk_m;
-                double CF = sixth * Hzk_0 - dt * AK_p / Hzk_0;
-                const double BC = third * (Hzk_m + Hzk_0) + dt * AK_0 * (oHzkm1 + oHz);
-                const double cff = 1.0 / (BC - FC * CFp);
-                CF *= cff;
-                const double DC = cff * (phi_0 - phi_m - FC * DCp);
-                sCF[k * 64] = CF; sDC[k * 64] = DC;
-                CFp = CF; DCp = DC; Hzk_m = Hzk_0; AK_m = AK_0; AK_0 = AK_p; phi_m = phi_0;
-            }
-        }
-    }
-    // ---- back-substitution fused with the viscosity update; results stay in LDS.  Here AK_0 = AK(N+1).
-    double DC_up = 0.0, DCs_up = DC_up * AK_0;
-#pragma unroll
-    for (int u = 0; u < VV_U; u++) {
-        const int k = N - u; const bool ok = k >= 0;
-        nP[u] = ok ? phi(ic, j, k) : 0.0; nR[u] = ok ? rphi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
-        nA[u] = ok ? Akv(ic, j, k) : 0.0; nAx[u] = ok ? ld2(Akv, k) : 0.0;
-    }
-    for (int kb = N; kb >= 0; kb -= VV_U) {
-        double cP[VV_U], cR[VV_U], cH[VV_U], cHx[VV_U], cA[VV_U], cAx[VV_U];
-#pragma unroll
-        for (int u = 0; u < VV_U; u++) { cP[u] = nP[u]; cR[u] = nR[u]; cH[u] = nH[u]; cHx[u] = nHx[u]; cA[u] = nA[u]; cAx[u] = nAx[u]; }
-#pragma unroll
-        for (int u = 0; u < VV_U; u++) {
-            const int k = kb - VV_U - u; const bool ok = k >= 0;
-            nP[u] = ok ? phi(ic, j, k) : 0.0; nR[u] = ok ? rphi(ic, j, k) : 0.0; nH[u] = ok ? Hz(ic, j, k) : 1.0; nHx[u] = ok ? ld2(Hz, k) : 1.0;
-            nA[u] = ok ? Akv(ic, j, k) : 0.0; nAx[u] = ok ? ld2(Akv, k) : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < VV_U; u++) {
-            const int k = kb - u;
-            const double hs = second(cH[u], cHx[u]) + cH[u];
-            const double Hzk = 0.5 * hs;
-            const double AKk = 0.5 * (second(cA[u], cAx[u]) + cA[u]);
-            if (k >= 0) {
-                double DC;
-                if (k >= 1) { DC = sDC[k * 64]; DC -= sCF[k * 64] * DC_up; }
-                else DC = 0.0;
-                const double DCs = DC * AKk;
-                const double oHz = 1.0 / Hzk;
-                const double cff = dt * oHz * (DCs_up - DCs);
-                sDC[k * 64] = ab3(cP[u], cR[u], hs) + cff;           // phi after vert_visc_3d
-                sCF[k * 64] = Hzk;
-                DC_up = DC; DCs_up = DCs;
-            }
-        }
-    }
-    // ---- vert_mean_3d: ascending sums in the reference's order (:22-34), then the correction (:36-46)
-    double CF = sCF[0], DCm = sDC[0] * CF;
-    for (int k = 1; k <= N; k++) { const double Hzf = sCF[k * 64]; CF += Hzf; DCm += sDC[k * 64] * Hzf; }
-    const double on = 2.0 / (dxlen(ii, jj, 0) + dxlen(ic, j, 0));
-    const double cff1 = 1.0 / (CF * (on));
-    DCm = (DCm * (on) - Davg1(ic, j, 0)) * cff1;
-    const double m = msk(ic, j, 0);
-    if (act)
-        for (int k = 0; k <= N; k++) { double x = sDC[k * 64]; x -= DCm; x *= m; phi(i, j, k) = x; }
-}
-
 // AB3 + vert_visc_3d + vert_mean_3d for u and v; *applied = 0 when the fused form does not apply (the caller runs the leaves)
 int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
 {
@@ -443,10 +344,10 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     RH_NEED(s->pm, bx_slab(xs, 2, 0)); RH_NEED(s->pn, bx_slab(xs, 2, 0)); RH_NEED(s->pm, bx_slab(ys, 2, 0)); RH_NEED(s->pn, bx_slab(ys, 2, 0));
     RH_NEED(s->DU_avg1, bx_slab(xbx, 2, 0)); RH_NEED(s->DV_avg1, bx_slab(ybx, 2, 0)); RH_NEED(s->msku, bx_slab(xbx, 2, 0)); RH_NEED(s->mskv, bx_slab(ybx, 2, 0));
     const dim3 gx((xbx.hi[0] - xbx.lo[0] + 64) / 64, xbx.hi[1] - xbx.lo[1] + 1, 1), gy((ybx.hi[0] - ybx.lo[0] + 64) / 64, ybx.hi[1] - ybx.lo[1] + 1, 1);
-    k_uv_corrector<1, 0><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn),
+    k_column_solver<1, 0, 1, VV_D_V><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn),
         mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab);
     RH_LAUNCH_CHECK();
-    k_uv_corrector<0, 1><<<gy, 64, lds_bytes, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm),
+    k_column_solver<0, 1, 1, VV_D_V><<<gy, 64, lds_bytes, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm),
         mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab);
     RH_LAUNCH_CHECK();
     *applied = 1;
