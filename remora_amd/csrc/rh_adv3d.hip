@@ -429,6 +429,78 @@ __global__ void k_massflux(B3 bx, int ioff, int joff, A4 phi, A4 phibar, A4 Hphi
     const double pb = DCi * a1;
     phibar(i, j, 0, 0) = pb; phibar(i, j, 0, 1) = pb;
 }
+// Same arithmetic, one wavefront per block and one column per lane, with DC(k) and the half-updated flux parked in LDS between
+// the integration sweep and the correction sweep (the slab form above re-reads Hz three times and writes Hphi twice), and the
+// operands of level k+D requested while level k is integrated (register ring, see k_column_solver).  Columns on a boundary face
+// (`edge`, :87-101) need the depth integral before their velocity is corrected: those few lanes redo their sums from memory.
+#define MF_D 10
+template <int IO, int JO, int D>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_massflux_lds(B3 bx, A4 phi, A4 phibar, A4 Hphi, A4 Hz, A4 pmn, A4 Davg1, A4 Davg2, A4 msk,
+               int N, int dlox, int dhix, int dloy, int dhiy, int perx, int pery)
+{
+    extern __shared__ double mf_lds[];
+    const int lane = threadIdx.x;
+    double *sD = mf_lds + lane, *sX = mf_lds + (size_t)(N + 1) * 64 + lane;        // s[k * 64]
+    const int i = bx.lo0 + (int)blockIdx.x * 64 + lane, j = bx.lo1 + (int)blockIdx.y;
+    const bool act = i <= bx.hi0;
+    const int ic = act ? i : bx.hi0;
+    const int ii = ic - IO, jj = j - JO;
+    const bool first = (IO == 1) && (lane == 0);
+    const double on = 2.0 / (pmn(ic, j, 0) + pmn(ii, jj, 0));
+    const bool edge = (ic == dlox - JO && !perx) || (ic == dhix + 1 && !perx) || (j == dloy - IO && !pery) || (j == dhiy + 1 && !pery);
+    struct L { double p, f, h, hx; };
+    auto load = [&](int k) -> L {
+        const int kc = k < N ? k : N;
+        L r; r.p = phi(ic, j, kc); r.f = Hphi(ic, j, kc); r.h = Hz(ic, j, kc);
+        r.hx = (IO == 1) ? (first ? Hz(ic - 1, j, kc) : 0.0) : Hz(ic, jj, kc);
+        return r;
+    };
+    double DCs = 0.0, CF = 0.0, FC = 0.0;
+    auto step = [&](int k, const L &c) {
+        double hx = c.hx;
+        if (IO == 1) { const double s = __shfl_up(c.h, 1); hx = first ? c.hx : s; }
+        const double DCk = 0.5 * on * (c.h + hx);                     // :44-50
+        DCs += DCk;
+        CF += DCk * c.p;
+        const double hp = 0.5 * (c.f + c.p * DCk);                    // :104-110 (valid for columns whose velocity is not corrected)
+        FC += hp;
+        sD[k * 64] = DCk; sX[k * 64] = hp;
+    };
+    L ring[D];
+#pragma unroll
+    for (int u = 0; u < D; u++) ring[u] = load(u);
+    int kb = 0;
+    for (; kb + D - 1 <= N; kb += D) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            step(kb + u, ring[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            ring[u] = load(kb + u + D);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < D; u++) if (kb + u <= N) step(kb + u, ring[u]);
+    const double DCi = 1.0 / DCs;
+    const double a1 = Davg1(ic, j, 0);
+    CF = DCi * (CF - a1);
+    if (edge) {                                                       // :87-101, then the flux sums again with the corrected velocity
+        const double m = msk(ic, j, 0);
+        FC = 0.0;
+        for (int k = 0; k <= N; k++) {
+            double x = phi(ic, j, k); x -= CF; x *= m;
+            if (act) phi(i, j, k) = x;
+            const double hp = 0.5 * (Hphi(ic, j, k) + x * sD[k * 64]);
+            sX[k * 64] = hp; FC += hp;
+        }
+    }
+    FC = DCi * (FC - Davg2(ic, j, 0));                                // :112-121
+    if (act) {
+        for (int k = 0; k <= N; k++) Hphi(i, j, k) = sX[k * 64] - sD[k * 64] * FC;
+        const double pb = DCi * a1;
+        phibar(i, j, 0, 0) = pb; phibar(i, j, 0, 1) = pb;
+    }
+}
 extern "C" int rh_update_massflux_3d(rh_ctx *c, rh_box bx, int ioff, int joff, rh_array4 phi, rh_array4 phibar, rh_array4 Hphi,
                                      rh_array4 Hz, rh_array4 pm_or_pn, rh_array4 Dphi_avg1, rh_array4 Dphi_avg2, rh_array4 msk, int N)
 {
@@ -440,8 +512,16 @@ extern "C" int rh_update_massflux_3d(rh_ctx *c, rh_box bx, int ioff, int joff, r
     if (phibar.ncomp < 2) return rh_fail("rh_update_massflux_3d: phibar needs 2 components");
     RH_NEED(phi, bx); RH_NEED(Hphi, bx); RH_NEED(Hz, bs); RH_NEED(pm_or_pn, bx_slab(bs, 2, 0));
     RH_NEED(phibar, b2); RH_NEED(Dphi_avg1, b2); RH_NEED(Dphi_avg2, b2); RH_NEED(msk, b2);
-    k_massflux<<<grid2(bx), rh_block(), 0, c->stream>>>(mkB(bx), ioff, joff, mkA(phi), mkA(phibar), mkA(Hphi), mkA(Hz), mkA(pm_or_pn),
-        mkA(Dphi_avg1), mkA(Dphi_avg2), mkA(msk), N, c->dom.lo[0], c->dom.hi[0], c->dom.lo[1], c->dom.hi[1], c->prm.periodic[0], c->prm.periodic[1]);
+    const size_t lds_bytes = sizeof(double) * 2 * (size_t)(N + 1) * 64;
+    if (!c->unfused && lds_bytes <= 64 * 1024) {
+        const dim3 grid((bx.hi[0] - bx.lo[0] + 64) / 64, bx.hi[1] - bx.lo[1] + 1, 1);
+#define RH_MF(IO, JO) k_massflux_lds<IO, JO, MF_D><<<grid, 64, lds_bytes, c->stream>>>(mkB(bx), mkA(phi), mkA(phibar), mkA(Hphi), mkA(Hz), mkA(pm_or_pn), \
+            mkA(Dphi_avg1), mkA(Dphi_avg2), mkA(msk), N, c->dom.lo[0], c->dom.hi[0], c->dom.lo[1], c->dom.hi[1], c->prm.periodic[0], c->prm.periodic[1])
+        if (ioff) RH_MF(1, 0); else RH_MF(0, 1);
+#undef RH_MF
+    } else
+        k_massflux<<<grid2(bx), rh_block(), 0, c->stream>>>(mkB(bx), ioff, joff, mkA(phi), mkA(phibar), mkA(Hphi), mkA(Hz), mkA(pm_or_pn),
+            mkA(Dphi_avg1), mkA(Dphi_avg2), mkA(msk), N, c->dom.lo[0], c->dom.hi[0], c->dom.lo[1], c->dom.hi[1], c->prm.periodic[0], c->prm.periodic[1]);
     RH_LAUNCH_CHECK(); return 0;
 }
 

@@ -148,12 +148,79 @@ __global__ void k_omega(B3 b, A4 W, A4 Huon, A4 Hvom, A4 z_w, A4 h, int N)
     for (int k = 1; k <= N; k++) W(i, j, k) = W(i, j, k) - wrk * (z_w(i, j, k) + hh);
     W(i, j, N + 1) = 0.0;
 }
+// Same sweep with the running integral w(k) parked in LDS ([k][lane], one wavefront per block, one column per lane) instead of
+// being written to W and read back, and with the operands of level k+D requested while level k is integrated (register ring,
+// see k_column_solver in rh_adv3d.hip).  Huon(i+1) comes from the neighbouring lane; only the last lane loads it.
+#define OM_D 12
+template <int D>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_omega_lds(B3 b, A4 W, A4 Huon, A4 Hvom, A4 z_w, A4 h, int N)
+{
+    extern __shared__ double om_lds[];
+    const int lane = threadIdx.x;
+    double *sW = om_lds + lane;                                       // sW[k * 64], k = 1 .. N+1
+    const int i = b.lo0 + (int)blockIdx.x * 64 + lane, j = b.lo1 + (int)blockIdx.y;
+    const bool act = i <= b.hi0;
+    const int ic = act ? i : b.hi0;
+    const bool edge = (lane == 63) || (ic == b.hi0);                  // no in-wave neighbour holding Huon(i+1)
+    struct L { double u, ux, v0, v1; };
+    auto load = [&](int kk) -> L {                                    // level kk (clamped) of the fluxes
+        const int kc = kk < N ? kk : N;
+        L r; r.u = Huon(ic, j, kc); r.ux = edge ? Huon(ic + 1, j, kc) : 0.0; r.v0 = Hvom(ic, j, kc); r.v1 = Hvom(ic, j + 1, kc); return r;
+    };
+    double w = 0.0;
+    auto step = [&](int k, const L &c) {                              // :102-109: W(k) = W(k-1) - dHuon(k-1) - dHvom(k-1)
+        const double un = __shfl_down(c.u, 1);
+        const double up = edge ? c.ux : un;
+        w = w - (up - c.u) - (c.v1 - c.v0);
+        sW[k * 64] = w;
+    };
+    L ring[D];
+#pragma unroll
+    for (int u = 0; u < D; u++) ring[u] = load(u);
+    int kb = 1;
+    for (; kb + D - 1 <= N + 1; kb += D) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            step(kb + u, ring[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            ring[u] = load(kb + u - 1 + D);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < D; u++) if (kb + u <= N + 1) step(kb + u, ring[u]);
+    // ---- remove the part proportional to (z_w + h), :111-125
+    const double hh = h(ic, j, 0, 0);
+    const double wrk = w / (z_w(ic, j, N + 1) + hh);
+    if (act) { W(i, j, 0) = 0.0; W(i, j, N + 1) = 0.0; }
+    double zr[D];
+#pragma unroll
+    for (int u = 0; u < D; u++) { const int k = 1 + u; zr[u] = z_w(ic, j, k < N ? k : N); }
+    kb = 1;
+    for (; kb + D - 1 <= N; kb += D) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            const int k = kb + u;
+            const double x = sW[k * 64] - wrk * (zr[u] + hh);
+            if (act) W(i, j, k) = x;
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = k + D; zr[u] = z_w(ic, j, kn < N ? kn : N);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < D; u++) { const int k = kb + u; if (k <= N) { const double x = sW[k * 64] - wrk * (zr[u] + hh); if (act) W(i, j, k) = x; } }
+}
 extern "C" int rh_omega(rh_ctx *c, rh_box gbx1, rh_array4 W, rh_array4 Huon, rh_array4 Hvom, rh_array4 z_w, rh_array4 h, int N)
 {
     TScope t(c, "omega");
     rh_box b = gbx1; b.lo[2] = 0; b.hi[2] = N; rh_box bw = b; bw.hi[2] = N + 1;
     RH_NEED(W, bw); RH_NEED(z_w, bw); RH_NEED(Huon, bx_nodal(b, 0)); RH_NEED(Hvom, bx_nodal(b, 1)); RH_NEED(h, bx_slab(b, 2, 0));
-    k_omega<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(W), mkA(Huon), mkA(Hvom), mkA(z_w), mkA(h), N);
+    const size_t lds_bytes = sizeof(double) * (size_t)(N + 2) * 64;
+    if (!c->unfused && lds_bytes <= 64 * 1024) {
+        const dim3 grid((b.hi[0] - b.lo[0] + 64) / 64, b.hi[1] - b.lo[1] + 1, 1);
+        k_omega_lds<OM_D><<<grid, 64, lds_bytes, c->stream>>>(mkB(b), mkA(W), mkA(Huon), mkA(Hvom), mkA(z_w), mkA(h), N);
+    } else
+        k_omega<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(W), mkA(Huon), mkA(Hvom), mkA(z_w), mkA(h), N);
     RH_LAUNCH_CHECK(); return 0;
 }
 
