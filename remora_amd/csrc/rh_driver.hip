@@ -31,6 +31,29 @@ static int set_analytical_vmix(rh_ctx *c, rh_state *s)
     return bcs.end();
 }
 
+__global__ void k_zero_box(B3 b, A4 a)
+{
+    RH_IJ(b); if (!inb2(b, i, j)) return;
+    a(i, j, b.lo2 + (int)blockIdx.z) = 0.0;
+}
+// a := 0 outside the i-j extent of `inner` (all k): what is left of a setVal(0) when the next kernel overwrites `inner` entirely
+static int zero_outside(rh_ctx *c, const rh_array4 &a, const rh_box &inner)
+{
+    const rh_box all = bx_of(a);
+    rh_box r[4] = {all, all, all, all};
+    r[0].hi[1] = inner.lo[1] - 1;                                               // rows below
+    r[1].lo[1] = inner.hi[1] + 1;                                               // rows above
+    r[2].lo[1] = inner.lo[1]; r[2].hi[1] = inner.hi[1]; r[2].hi[0] = inner.lo[0] - 1;   // columns left
+    r[3].lo[1] = inner.lo[1]; r[3].hi[1] = inner.hi[1]; r[3].lo[0] = inner.hi[0] + 1;   // columns right
+    for (rh_box &q : r) {
+        q = bx_and(q, all);
+        if (!bx_ok(q)) continue;
+        k_zero_box<<<grid3(q), rh_block(), 0, c->stream>>>(mkB(q), mkA(a));
+        RH_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // REMORA::setup_step, REMORA_setup_step.cpp:7-369 (+ REMORA::prestep, REMORA_prestep.cpp:36-185)
 extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
@@ -71,7 +94,8 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     RH_TRY(rh_rho_eos(c, bx_grow(bx, 2, 2, 0), s->cons_old, c->rho, s->rhoA, s->rhoS, s->bvf, s->Hz, s->z_w, s->z_r, s->h, s->mskr, N));   // :200
     RH_TRY(set_analytical_vmix(c, s));                                                             // :203-206
     RH_TRY(launch_set_zeta(c, s));                                                                 // :208
-    RH_TRY(dev_setval(c, c->W, 0, 1, 0.0));                                                        // :210-211
+    // :210-211 mf_W.setVal(0): omega overwrites every level of the grow-1 box, so only the frame around it needs the zero
+    if (P.use_prestep) RH_TRY(zero_outside(c, c->W, bx_grow(bx, 1, 1, 0))); else RH_TRY(dev_setval(c, c->W, 0, 1, 0.0));
     bool fused_t = false;
     if (P.use_prestep) {                                                                           // :216, REMORA_prestep.cpp
         RH_TRY(rh_omega(c, bx_grow(bx, 1, 1, 0), c->W, s->Huon, s->Hvom, s->z_w, s->h, N));        // prestep_t_advection.cpp:97-125 (identical for all tracers)
@@ -141,7 +165,7 @@ static int advance_3d(rh_ctx *c, rh_state *s, int istep)
     }
     RH_TRY(rh_update_massflux_3d(c, gbx2, 1, 0, s->xvel_new, s->ubar, s->Huon, s->Hz, s->pn, s->DU_avg1, s->DU_avg2, s->msku, N));   // :213
     RH_TRY(rh_update_massflux_3d(c, gbx2, 0, 1, s->yvel_new, s->vbar, s->Hvom, s->Hz, s->pm, s->DV_avg1, s->DV_avg2, s->mskv, N));   // :218
-    RH_TRY(dev_setval(c, c->W, 0, 1, 0.0));                                                        // :230-231
+    RH_TRY(zero_outside(c, c->W, gbx1));                                                           // :230-231 (omega overwrites gbx1)
     RH_TRY(rh_omega(c, gbx1, c->W, s->Huon, s->Hvom, s->z_w, s->h, N));                            // :272-293
     if (!c->unfused) RH_TRY(launch_rhs_t3(c, s));                                                  // :341-346, 3 tracers in one sweep
     else for (int n = 0; n < RH_NCONS; n++)

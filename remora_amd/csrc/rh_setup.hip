@@ -328,30 +328,27 @@ extern "C" int rh_prestep_t(rh_ctx *c, rh_box tbx, rh_array4 told, rh_array4 tne
 __global__ void k_prestep_uv(B3 bx, int ioff, int joff, A4 vel, A4 vel_old, A4 rvel, A4 Hz, A4 sstr, A4 bstr, A4 pm, A4 pn,
                              int step, int nrhs, int N, double dt)
 {
+    // no level depends on another (lambda = 1 removes the vertical flux divergence): one thread per point, grid.z walks k
     RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const int k = bx.lo2 + (int)blockIdx.z;
     const int ii = i - ioff, jj = j - joff;
-    const double DC = 0.25 * dt * (pm(i, j, 0) + pm(ii, jj, 0)) * (pn(i, j, 0) + pn(ii, jj, 0));
-    const double sb = dt * bstr(i, j, 0), ss = dt * sstr(i, j, 0);
     const int indx = nrhs ? 0 : 1;
-    for (int k = 0; k <= N; k++) {
-        const double a = vel_old(i, j, k) * 0.5 * (Hz(i, j, k) + Hz(ii, jj, k));
-        // FC(k) = dt*(1-lambda)*... = 0 for k < N, FC(N) = dt*sstr
-        const double b = (k == 0) ? 0.0 - sb : (k == N ? ss - 0.0 : 0.0 - 0.0);
-        if (step == 0) vel(i, j, k) = a + b;
-        else {
-            const double r_indx = rvel(i, j, k, indx), r_nrhs = rvel(i, j, k, nrhs);
-            // swap
-            rvel(i, j, k, indx) = r_nrhs;
-            if (step == 1) {
-                rvel(i, j, k, nrhs) = r_indx;
-                const double cff3 = 0.5 * DC;
-                vel(i, j, k) = a - cff3 * r_nrhs + b;
-            } else {
-                const double cff1 = 5.0 / 12.0, cff2 = 16.0 / 12.0;
-                vel(i, j, k) = a + DC * (cff1 * r_indx - cff2 * r_nrhs) + b;
-                rvel(i, j, k, nrhs) = 0.0;
-            }
-        }
+    const double a = vel_old(i, j, k) * 0.5 * (Hz(i, j, k) + Hz(ii, jj, k));
+    // FC(k) = dt*(1-lambda)*... = 0 for k < N, FC(N) = dt*sstr
+    double b;
+    if (k == 0) b = 0.0 - dt * bstr(i, j, 0); else if (k == N) b = dt * sstr(i, j, 0) - 0.0; else b = 0.0 - 0.0;
+    if (step == 0) { vel(i, j, k) = a + b; return; }
+    const double DC = 0.25 * dt * (pm(i, j, 0) + pm(ii, jj, 0)) * (pn(i, j, 0) + pn(ii, jj, 0));
+    const double r_indx = rvel(i, j, k, indx), r_nrhs = rvel(i, j, k, nrhs);
+    rvel(i, j, k, indx) = r_nrhs;                                     // swap
+    if (step == 1) {
+        rvel(i, j, k, nrhs) = r_indx;
+        const double cff3 = 0.5 * DC;
+        vel(i, j, k) = a - cff3 * r_nrhs + b;
+    } else {
+        const double cff1 = 5.0 / 12.0, cff2 = 16.0 / 12.0;
+        vel(i, j, k) = a + DC * (cff1 * r_indx - cff2 * r_nrhs) + b;
+        rvel(i, j, k, nrhs) = 0.0;
     }
 }
 extern "C" int rh_prestep_uv(rh_ctx *c, rh_box vel_bx, int ioff, int joff, rh_array4 vel, rh_array4 vel_old, rh_array4 rvel,
@@ -367,7 +364,7 @@ extern "C" int rh_prestep_uv(rh_ctx *c, rh_box vel_bx, int ioff, int joff, rh_ar
     RH_NEED(vel, vel_bx); RH_NEED(vel_old, vel_bx); RH_NEED(rvel, vel_bx); RH_NEED(Hz, bs);
     RH_NEED(sstr, b2); RH_NEED(bstr, b2); RH_NEED(pm, bs2); RH_NEED(pn, bs2);
     const int step = (iic == ntfirst) ? 0 : (iic == ntfirst + 1 ? 1 : 2);
-    k_prestep_uv<<<grid2(vel_bx), rh_block(), 0, c->stream>>>(mkB(vel_bx), ioff, joff, mkA(vel), mkA(vel_old), mkA(rvel), mkA(Hz),
+    k_prestep_uv<<<grid3(vel_bx), rh_block(), 0, c->stream>>>(mkB(vel_bx), ioff, joff, mkA(vel), mkA(vel_old), mkA(rvel), mkA(Hz),
         mkA(sstr), mkA(bstr), mkA(pm), mkA(pn), step, nrhs, N, dt);
     RH_LAUNCH_CHECK(); return 0;
 }

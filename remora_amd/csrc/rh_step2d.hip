@@ -32,6 +32,7 @@ struct ZetaPar {
     int do_step;             // my_iif < nfast
     int zmode;               // 0: my_iif == 0 (forward Euler), 1: predictor (leap-frog), 2: corrector (Adams-Moulton)
     int predictor;
+    int nomask;              // rh_params.masks_all_one: mskr == 1 everywhere, x * 1.0 == x, so the mask is not read
     double dtfast;
 };
 
@@ -57,20 +58,21 @@ __global__ void k2d_zeta(B3 g3, B3 xg, B3 yg, B3 t1, ZetaPar zp, A4 zeta_rhs, A4
     // ---- free surface, :379-464
     const double div = (DUon(i, j, 0) - DUon(i + 1, j, 0)) + (DVom(i, j, 0) - DVom(i, j + 1, 0));
     const double zs = zeta_stp(i, j, 0);
+    const double mr = zp.nomask ? 1.0 : mskr(i, j, 0);
     double zn, zw;
     if (zp.zmode == 0) {
         const double cff1 = zp.dtfast;
-        zn = (zs + pm(i, j, 0) * pn(i, j, 0) * cff1 * div) * mskr(i, j, 0);
+        zn = (zs + pm(i, j, 0) * pn(i, j, 0) * cff1 * div) * mr;
         zw = 0.5 * (zs + zn);
     } else if (zp.zmode == 1) {
         const double cff1 = 2.0 * zp.dtfast, cff4 = 4.0 / 25.0, cff5 = 1.0 - 2.0 * cff4;
-        zn = (zs + pm(i, j, 0) * pn(i, j, 0) * cff1 * div) * mskr(i, j, 0);
+        zn = (zs + pm(i, j, 0) * pn(i, j, 0) * cff1 * div) * mr;
         zw = cff5 * zeta_rhs(i, j, 0) + cff4 * (zs + zn);
     } else {
         const double cff1 = zp.dtfast * 5.0 / 12.0, cff2 = zp.dtfast * 8.0 / 12.0, cff3 = zp.dtfast * 1.0 / 12.0, cff4 = 2.0 / 5.0, cff5 = 1.0 - cff4;
         const double cff = cff1 * div;
         zn = zs + pm(i, j, 0) * pn(i, j, 0) * (cff + cff2 * rzeta_stp(i, j, 0) - cff3 * rzeta_pts(i, j, 0));
-        zn *= mskr(i, j, 0);
+        zn *= mr;
         zw = cff5 * zn + cff4 * zeta_rhs(i, j, 0);
     }
     zwrk_o(i, j, 0) = zw;        // Dnew, gzeta, gzeta2, gzetaSA (:392-394 ...) are rebuilt from zwrk / rhoS / rhoA / zeta(knew) / h in k2d_uvbar
@@ -83,6 +85,7 @@ struct UVPar {
     int couple;              // 0: rhs += rufrc ; 1: iic == ntfirst ; 2: iic == ntfirst+1 ; 3: later (first && predictor), :543-624
     int am3;                 // 0: my_iif == 0 || predictor (:643-684) ; 1: corrector (:686-713)
     int predictor;
+    int nomask;              // rh_params.masks_all_one: msku, mskv, mskp are 1 everywhere and are not read
     double g, c1, c2, c3;    // step coefficients
 };
 
@@ -147,6 +150,8 @@ __device__ __forceinline__ double s2_VFe(const TA &v, const TB &DV, int i, int j
 }
 
 // Drhs = zeta(krhs) + h, rebuilt where it is used (bitwise the value of the reference's Drhs scratch FAB, :149-152)
+// mask view that skips the load when the masks are known to be 1 (x * 1.0 == x bit for bit)
+struct MaskView { A4 m; int one; __device__ __forceinline__ double operator()(int i, int j, int) const { return one ? 1.0 : m(i, j, 0); } };
 struct DrhsView { A4 z, h; __device__ __forceinline__ double operator()(int i, int j, int) const { return z(i, j, 0) + h(i, j, 0); } };
 
 // Flux sharing through LDS.  Every flux of the reference's scratch FABs (UFx, UFe, VFx, VFe of rhs_uv_2d and of uv3dmix, the
@@ -194,7 +199,7 @@ k2d_uvbar(B3 xb, B3 yb, B3 un, B3 rb, UVPar P, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, 
     if (inb2(un, i, j)) {                                   // psi point (i,j), nodes lo .. hi+1
         UFe = s2_UFe(ub_rhs, DVom, i, j, P);                                                 // :107-129
         VFx = s2_VFx(vb_rhs, DUon, i, j, P);                                                 // :171-191
-        const MixP p = mix_p_metrics(pm, pn, visc2_p, mskp, i, j);                           // uv3dmix :61-78, :117-134
+        const MixP p = mix_p_metrics(pm, pn, visc2_p, MaskView{mskp, P.nomask}, i, j);       // uv3dmix :61-78, :117-134
         const double cffp = mix_p_cff(p, Drhs, ub_rhs, vb_rhs, i, j, 0);
         mUFe = p.om_p * p.om_p * p.visc * cffp;
         mVFx = p.on_p * p.on_p * p.visc * cffp;
@@ -244,9 +249,10 @@ k2d_uvbar(B3 xb, B3 yb, B3 un, B3 rb, UVPar P, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, 
         const double Dstp0 = zeta_stp(i, j, 0) + h0, Dstp1 = zeta_stp(i - 1, j, 0) + hx;     // :626-713
         const double cff = (pm0 + pmx) * (pn0 + pnx);
         const double Dnew_avg = 1.0 / ((zeta_new(i, j, 0) + h0) + (zeta_new(i - 1, j, 0) + hx));
-        if (!P.am3) ub_new(i, j, 0) = (ub_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * msku(i, j, 0);
+        const double mu = P.nomask ? 1.0 : msku(i, j, 0);
+        if (!P.am3) ub_new(i, j, 0) = (ub_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mu;
         else ub_new(i, j, 0) = (ub_stp(i, j, 0) * (Dstp0 + Dstp1) +
-                                cff * (P.c1 * rhs + P.c2 * rubar_stp(i, j, 0) - P.c3 * rubar_pts(i, j, 0))) * Dnew_avg * msku(i, j, 0);
+                                cff * (P.c1 * rhs + P.c2 * rubar_stp(i, j, 0) - P.c3 * rubar_pts(i, j, 0))) * Dnew_avg * mu;
         if (P.predictor) rubar_rhs(i, j, 0) = rhs;                                           // :721-730
     }
     if (tx <= RT_BX - 2 && ty >= 1 && inb2(yb, i, j)) {
@@ -289,9 +295,10 @@ k2d_uvbar(B3 xb, B3 yb, B3 un, B3 rb, UVPar P, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, 
         const double Dstp0 = zeta_stp(i, j, 0) + h0, Dstp1 = zeta_stp(i, j - 1, 0) + hy;
         const double cff = (pm0 + pmy) * (pn0 + pny);
         const double Dnew_avg = 1.0 / ((zeta_new(i, j, 0) + h0) + (zeta_new(i, j - 1, 0) + hy));
-        if (!P.am3) vb_new(i, j, 0) = (vb_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mskv(i, j, 0);
+        const double mv = P.nomask ? 1.0 : mskv(i, j, 0);
+        if (!P.am3) vb_new(i, j, 0) = (vb_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mv;
         else vb_new(i, j, 0) = (vb_stp(i, j, 0) * (Dstp0 + Dstp1) +
-                                cff * (P.c1 * rhs + P.c2 * rvbar_stp(i, j, 0) - P.c3 * rvbar_pts(i, j, 0))) * Dnew_avg * mskv(i, j, 0);
+                                cff * (P.c1 * rhs + P.c2 * rvbar_stp(i, j, 0) - P.c3 * rvbar_pts(i, j, 0))) * Dnew_avg * mv;
         if (P.predictor) rvbar_rhs(i, j, 0) = rhs;
     }
 }
@@ -316,6 +323,7 @@ static UVPar uvpar_base(const rh_ctx *c)
     UVPar P; memset(&P, 0, sizeof P);
     P.dlox = c->dom.lo[0]; P.dhix = c->dom.hi[0]; P.dloy = c->dom.lo[1]; P.dhiy = c->dom.hi[1];
     P.perx = c->prm.periodic[0]; P.pery = c->prm.periodic[1]; P.uv_c2 = c->prm.uv_c2; P.use_cor = c->prm.use_coriolis; P.g = c->prm.g;
+    P.nomask = c->prm.masks_all_one ? 1 : 0;
     return P;
 }
 static int need_uv2d_stencil(const rh_box &xb, const rh_box &yb, const rh_array4 &ub, const rh_array4 &vb, const rh_array4 &DUon, const rh_array4 &DVom)
@@ -382,7 +390,7 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
 
     // ---- averages + free surface
     ZetaPar zp; memset(&zp, 0, sizeof zp);
-    zp.predictor = predictor ? 1 : 0; zp.dtfast = dtfast; zp.do_step = my_iif < nfast;
+    zp.predictor = predictor ? 1 : 0; zp.dtfast = dtfast; zp.do_step = my_iif < nfast; zp.nomask = c->prm.masks_all_one ? 1 : 0;
     if (predictor) {
         if (first) { zp.avg_mode = 0; zp.wt_b = (-1.0 / 12.0) * w2[my_iif + 1]; }
         else {

@@ -68,6 +68,21 @@ def test_leaf_entry_points_against_oracle(case, monkeypatch):
     rem.close(); orc.close()
 
 
+@pytest.mark.parametrize("case", ["Seamount", "DoubleGyre"])
+def test_mask_reading_path(case):
+    """masks_all_one = 0 makes every kernel read mskr/msku/mskv/mskp and run the final cons *= mskr pass
+    (REMORA_advance_3d_ml.cpp:51-62); with the all-ones masks of the pinned cases the result must not change by a bit."""
+    cfg = cases.get(case)
+    orc = Oracle(cfg)
+    cfg_m = dict(cfg, masks_all_one=0)
+    rem = REMORA(cfg_m)
+    upload_oracle_state(orc, rem)
+    for step in range(2):
+        orc.advance(1); rem.timeStep()
+        _check(compare_states(orc, rem), case, f"masked step {step}")
+    rem.close(); orc.close()
+
+
 @pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection"])
 def test_gold_plotfile(case):
     """Device-side initial state + ten steps through REMORA::Advance == the reference's regression test."""
