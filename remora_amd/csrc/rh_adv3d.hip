@@ -81,7 +81,7 @@ extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
 __global__ void k_uv_ab3(B3 xb, B3 yb, B3 un, A4 u, A4 v, A4 ru, A4 rv, A4 Hz, A4 pm, A4 pn, int nrhs, double cff)
 {
     RH_IJ(un);
-    const int k = un.lo2 + (int)blockIdx.z;
+    const int k = un.lo2 + RH_KZ;
     if (inb2(xb, i, j)) {
         double x = u(i, j, k);
         x += cff * (pm(i, j, 0) + pm(i - 1, j, 0)) * (pn(i, j, 0) + pn(i - 1, j, 0)) * ru(i, j, k, nrhs);
@@ -180,7 +180,8 @@ k_column_solver(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm
     extern __shared__ double vv_lds[];
     const int lane = threadIdx.x;
     double *sCF = vv_lds + lane, *sDC = vv_lds + (size_t)(N + 2) * 64 + lane;      // s[k * 64]
-    const int i = bx.lo0 + (int)blockIdx.x * 64 + lane, j = bx.lo1 + (int)blockIdx.y;
+    const RhTile rh_t_ = rh_tile();
+    const int i = bx.lo0 + rh_t_.x * 64 + lane, j = bx.lo1 + rh_t_.y;
     const bool act = i <= bx.hi0;
     const int ic = act ? i : bx.hi0;                       // inactive lanes shadow the last column (no stores)
     const int ii = ic - IO, jj = j - JO;
@@ -442,7 +443,8 @@ k_massflux_lds(B3 bx, A4 phi, A4 phibar, A4 Hphi, A4 Hz, A4 pmn, A4 Davg1, A4 Da
     extern __shared__ double mf_lds[];
     const int lane = threadIdx.x;
     double *sD = mf_lds + lane, *sX = mf_lds + (size_t)(N + 1) * 64 + lane;        // s[k * 64]
-    const int i = bx.lo0 + (int)blockIdx.x * 64 + lane, j = bx.lo1 + (int)blockIdx.y;
+    const RhTile rh_t_ = rh_tile();
+    const int i = bx.lo0 + rh_t_.x * 64 + lane, j = bx.lo1 + rh_t_.y;
     const bool act = i <= bx.hi0;
     const int ic = act ? i : bx.hi0;
     const int ii = ic - IO, jj = j - JO;
@@ -611,7 +613,8 @@ k_tracers_tiled(B3 bx, A4 adv /* cons_old | sstore */, A4 cnew, A4 sst, A4 Hz, A
     __shared__ double lds[2 * SET + NINV * NT];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
     double *inv = lds + 2 * SET + tid;                 // inv[q * NT]: conflict-free
-    const int i0 = bx.lo0 + (int)blockIdx.x * RT_BX, j0 = bx.lo1 + (int)blockIdx.y * RT_BY;
+    const RhTile rh_t_ = rh_tile();
+    const int i0 = bx.lo0 + rh_t_.x * RT_BX, j0 = bx.lo1 + rh_t_.y * RT_BY;
     const int i = i0 + tx, j = j0 + ty;
     const bool act = inb2(bx, i, j);
     const int N = P.N;
@@ -777,7 +780,7 @@ int launch_rhs_t3(rh_ctx *c, rh_state *s) { TScope t(c, "rhs_t3"); return tracer
 __global__ void k_mask_cons(B3 bx, A4 cons, A4 mskr, int nc)
 {
     RH_IJ(bx); if (!inb2(bx, i, j)) return;
-    const int k = bx.lo2 + (int)blockIdx.z;
+    const int k = bx.lo2 + RH_KZ;
     const double m = mskr(i, j, 0);
     for (int n = 0; n < nc; n++) cons(i, j, k, n) *= m;
 }

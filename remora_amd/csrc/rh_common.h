@@ -67,7 +67,23 @@ static inline dim3 grid3(const rh_box &b)
 // column kernels / 2-D kernels: one thread per (i,j)
 static inline dim3 grid2(const rh_box &b)
 { return dim3((b.hi[0]-b.lo[0]+RH_BX)/RH_BX, (b.hi[1]-b.lo[1]+RH_BY)/RH_BY, 1); }
-#define RH_IJ(b) const int i = (b).lo0 + (int)(blockIdx.x * RH_BX + threadIdx.x); const int j = (b).lo1 + (int)(blockIdx.y * RH_BY + threadIdx.y)
+// XCD-aware tile order (cdna_hip_programming.md T1).  Workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest),
+// each XCD with a private L2, so tiles that are neighbours in memory land on different L2s and every shared row or halo is
+// fetched over the fabric once per sharer (measured: 1.4-3x the algorithmic bytes, profiles/r1_v3_traffic.json).  This
+// bijective remap hands each group of workgroups that share an XCD a contiguous run of tiles (x fastest, then y, then z), so the
+// neighbours' rows are found in the XCD's own L2.  Pure performance choice: any mapping gives the same results.
+struct RhTile { int x, y, z; };
+__device__ __forceinline__ RhTile rh_tile()
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy * gridDim.z;
+    const unsigned orig = (blockIdx.z * gy + blockIdx.y) * gx + blockIdx.x;
+    const unsigned q = n / 8, r = n % 8, xcd = orig % 8;
+    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    RhTile o; o.x = (int)(t % gx); const unsigned u = t / gx; o.y = (int)(u % gy); o.z = (int)(u / gy);
+    return o;
+}
+#define RH_IJ(b) const RhTile rh_t_ = rh_tile(); const int i = (b).lo0 + rh_t_.x * RH_BX + (int)threadIdx.x; const int j = (b).lo1 + rh_t_.y * RH_BY + (int)threadIdx.y
+#define RH_KZ rh_t_.z      /* grid.z index of a pointwise 3-D kernel (after RH_IJ) */
 
 extern thread_local std::string g_rh_err;
 int rh_fail(const char *fmt, ...);

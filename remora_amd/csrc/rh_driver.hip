@@ -34,7 +34,7 @@ static int set_analytical_vmix(rh_ctx *c, rh_state *s)
 __global__ void k_zero_box(B3 b, A4 a)
 {
     RH_IJ(b); if (!inb2(b, i, j)) return;
-    a(i, j, b.lo2 + (int)blockIdx.z) = 0.0;
+    a(i, j, b.lo2 + RH_KZ) = 0.0;
 }
 // a := 0 outside the i-j extent of `inner` (all k): what is left of a setVal(0) when the next kernel overwrites `inner` entirely
 static int zero_outside(rh_ctx *c, const rh_array4 &a, const rh_box &inner)
@@ -245,7 +245,7 @@ __global__ void k_init_h(B3 b, A4 h, InitPar q)
 __global__ void k_init_cons(B3 b, A4 st, A4 z_r, InitPar q)
 {
     RH_IJ(b); if (!inb2(b, i, j)) return;
-    const int k = b.lo2 + (int)blockIdx.z;
+    const int k = b.lo2 + RH_KZ;
     const double z = z_r(i, j, k);
     if (q.prob == 0) { st(i, j, k, 0) = q.T0 + 8.0 * exp(z / 50.0); if (q.use_salt) st(i, j, k, 1) = q.S0; st(i, j, k, 2) = 0.0; }          // Upwelling/prob.cpp:101-161
     else if (q.prob == 1) { st(i, j, k, 0) = q.T0 + 7.5 * exp(z / 1000.0); if (q.use_salt) st(i, j, k, 1) = q.S0; st(i, j, k, 2) = 0.0; } // Seamount/prob.cpp:93-165
@@ -270,7 +270,7 @@ __global__ void k_init_cons(B3 b, A4 st, A4 z_r, InitPar q)
 __global__ void k_setbox(B3 b, A4 a, double v)
 {
     RH_IJ(b); if (!inb2(b, i, j)) return;
-    const int k = b.lo2 + (int)blockIdx.z;
+    const int k = b.lo2 + RH_KZ;
     a(i, j, k) = v;
 }
 // depth-mean velocity, Initialization/REMORA_init.cpp:97-154
@@ -408,7 +408,7 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
 __global__ void k_plot(B3 b, A4 cons, A4 u, A4 v, A4 w, double *__restrict__ out, int with_scalar)
 {
     RH_IJ(b); if (!inb2(b, i, j)) return;
-    const int k = b.lo2 + (int)blockIdx.z;
+    const int k = b.lo2 + RH_KZ;
     const long nx = b.hi0 - b.lo0 + 1, ny = b.hi1 - b.lo1 + 1, nz = b.hi2 - b.lo2 + 1, n3 = nx * ny * nz;
     const long q = (long)(i - b.lo0) + (long)(j - b.lo1) * nx + (long)(k - b.lo2) * nx * ny;
     int nc = 0;

@@ -33,7 +33,7 @@ int launch_bstress(rh_ctx *c, rh_state *s)
 __global__ void k_massflux_old(B3 bu, B3 bv, B3 un, A4 Hz, A4 Huon, A4 Hvom, A4 uold, A4 vold, A4 pm, A4 pn)
 {
     RH_IJ(un);
-    const int k = un.lo2 + (int)blockIdx.z;
+    const int k = un.lo2 + RH_KZ;
     if (inb2(bu, i, j)) { const double on_u = 2.0 / (pn(i - 1, j, 0) + pn(i, j, 0)); Huon(i, j, k) = 0.5 * (Hz(i, j, k) + Hz(i - 1, j, k)) * uold(i, j, k) * on_u; }
     if (inb2(bv, i, j)) { const double om_v = 2.0 / (pm(i, j - 1, 0) + pm(i, j, 0)); Hvom(i, j, k) = 0.5 * (Hz(i, j, k) + Hz(i, j - 1, k)) * vold(i, j, k) * om_v; }
 }
@@ -96,7 +96,7 @@ extern "C" int rh_rho_eos(rh_ctx *c, rh_box bx, rh_array4 state, rh_array4 rho, 
 __global__ void k_vmix(B3 b, A4 Akv, A4 Akt, A4 z_w, int mode, double akv0, double akt0, double akt1, double akt2)
 {
     RH_IJ(b); if (!inb2(b, i, j)) return;
-    const int k = b.lo2 + (int)blockIdx.z;
+    const int k = b.lo2 + RH_KZ;
     if (mode == RH_VMIX_UPWELLING) {
         Akv(i, j, k) = 2.0e-03 + 8.0e-03 * exp(z_w(i, j, k) / 150.0);
         Akt(i, j, k, 0) = 1.0e-6; Akt(i, j, k, 1) = 1.0e-6; Akt(i, j, k, 2) = 0.0;
@@ -159,7 +159,8 @@ k_omega_lds(B3 b, A4 W, A4 Huon, A4 Hvom, A4 z_w, A4 h, int N)
     extern __shared__ double om_lds[];
     const int lane = threadIdx.x;
     double *sW = om_lds + lane;                                       // sW[k * 64], k = 1 .. N+1
-    const int i = b.lo0 + (int)blockIdx.x * 64 + lane, j = b.lo1 + (int)blockIdx.y;
+    const RhTile rh_t_ = rh_tile();
+    const int i = b.lo0 + rh_t_.x * 64 + lane, j = b.lo1 + rh_t_.y;
     const bool act = i <= b.hi0;
     const int ic = act ? i : b.hi0;
     const bool edge = (lane == 63) || (ic == b.hi0);                  // no in-wave neighbour holding Huon(i+1)
@@ -330,7 +331,7 @@ __global__ void k_prestep_uv(B3 bx, int ioff, int joff, A4 vel, A4 vel_old, A4 r
 {
     // no level depends on another (lambda = 1 removes the vertical flux divergence): one thread per point, grid.z walks k
     RH_IJ(bx); if (!inb2(bx, i, j)) return;
-    const int k = bx.lo2 + (int)blockIdx.z;
+    const int k = bx.lo2 + RH_KZ;
     const int ii = i - ioff, jj = j - joff;
     const int indx = nrhs ? 0 : 1;
     const double a = vel_old(i, j, k) * 0.5 * (Hz(i, j, k) + Hz(ii, jj, k));
@@ -425,7 +426,7 @@ __global__ void k_prsgrd_uv(B3 ub, B3 vb, B3 un, A4 ru, A4 rv, A4 pn, A4 pm, A4 
                             int nrhs, double HalfGRho)
 {
     RH_IJ(un);
-    const int k = un.lo2 + (int)blockIdx.z;
+    const int k = un.lo2 + RH_KZ;
     const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
     if (inb2(ub, i, j)) {
         const double r2 = rho(i - 2, j, k), r1 = rho(i - 1, j, k), r0 = rho(i, j, k), rp = rho(i + 1, j, k);
@@ -489,7 +490,7 @@ extern "C" int rh_prsgrd(rh_ctx *c, rh_box phi_bx, rh_box utbx, rh_box vtbx, rh_
 __global__ void k_t3dmix(B3 bx, A4 st, A4 rhs, A4 d2, int d2k, A4 Hz, A4 pm, A4 pn, A4 msku, A4 mskv, double dt)
 {
     RH_IJ(bx); if (!inb2(bx, i, j)) return;
-    const int k = bx.lo2 + (int)blockIdx.z;
+    const int k = bx.lo2 + RH_KZ;
     const double r0 = rhs(i, j, k), hz0 = Hz(i, j, k);
     double FX0, FX1, FE0, FE1;
     {
@@ -702,7 +703,8 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
     __shared__ double lds[2 * SET + NINV * NT];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
     double *inv = lds + 2 * SET + tid;
-    const int i0 = un.lo0 + (int)blockIdx.x * RT_BX, j0 = un.lo1 + (int)blockIdx.y * RT_BY;
+    const RhTile rh_t_ = rh_tile();
+    const int i0 = un.lo0 + rh_t_.x * RT_BX, j0 = un.lo1 + rh_t_.y * RT_BY;
     const int i = i0 + tx, j = j0 + ty;
     const bool au = inb2(xb, i, j), av = inb2(yb, i, j);
     // k-invariants: Coriolis factors fomn at (i,j), (i-1,j), (i,j-1); stress terms; running vertical integrals

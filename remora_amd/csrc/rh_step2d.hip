@@ -173,7 +173,8 @@ k2d_uvbar(B3 xb, B3 yb, B3 un, B3 rb, UVPar P, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, 
     constexpr int NT = RT_BX * U_BY;
     __shared__ double lds[Q_N * NT];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
-    const int i = un.lo0 - 1 + (int)blockIdx.x * U_SX + tx, j = un.lo1 - 1 + (int)blockIdx.y * U_SY + ty;
+    const RhTile rh_t_ = rh_tile();
+    const int i = un.lo0 - 1 + rh_t_.x * U_SX + tx, j = un.lo1 - 1 + rh_t_.y * U_SY + ty;
     double *q = lds + tid;                                  // q[Q * NT]: this thread's slot of quantity Q
     const DrhsView Drhs{zeta_rhs, h};
     const double fac = 1000.0 / 1025.0;
