@@ -613,7 +613,7 @@ k_tracers_tiled(B3 bx, A4 adv /* cons_old | sstore */, A4 cnew, A4 sst, A4 Hz, A
     __shared__ double lds[2 * SET + NINV * NT];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
     double *inv = lds + 2 * SET + tid;                 // inv[q * NT]: conflict-free
-    const RhTile rh_t_ = rh_tile();
+    const RhTile rh_t_ = rh_tile_patch<8, 4>();          // one block per CU (LDS): 32 resident per XCD
     const int i0 = bx.lo0 + rh_t_.x * RT_BX, j0 = bx.lo1 + rh_t_.y * RT_BY;
     const int i = i0 + tx, j = j0 + ty;
     const bool act = inb2(bx, i, j);

@@ -82,6 +82,25 @@ __device__ __forceinline__ RhTile rh_tile()
     RhTile o; o.x = (int)(t % gx); const unsigned u = t / gx; o.y = (int)(u % gy); o.z = (int)(u / gy);
     return o;
 }
+// Variant for the k-marching tiled kernels.  Their blocks live for the whole column march, and two tiles share halo rows level by
+// level, so sharing an L2 only pays if both are at the same level at the same time.  The blocks resident on an XCD start together
+// (and, doing equal work, retire together), so the XCD's run of tiles is walked in compact PX x PY patches: a patch is what is
+// resident at once, and most halo rows are shared inside it.
+template <int PX, int PY>
+__device__ __forceinline__ RhTile rh_tile_patch()
+{
+    const unsigned gx = gridDim.x, gy = gridDim.y, n = gx * gy;
+    const unsigned orig = blockIdx.y * gx + blockIdx.x;
+    const unsigned q = n / 8, r = n % 8, xcd = orig % 8;
+    const unsigned t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+    const unsigned pr = t / (gx * PY), rem = t - pr * gx * PY;                  // patch row (every earlier one is full height)
+    const unsigned h = min((unsigned)PY, gy - pr * PY);
+    const unsigned pc = rem / (PX * h), rem2 = rem - pc * PX * h;               // patch in that row (every earlier one is full width)
+    const unsigned w = min((unsigned)PX, gx - pc * PX);
+    const unsigned ly = rem2 / w, lx = rem2 - ly * w;
+    RhTile o; o.x = (int)(pc * PX + lx); o.y = (int)(pr * PY + ly); o.z = 0;
+    return o;
+}
 #define RH_IJ(b) const RhTile rh_t_ = rh_tile(); const int i = (b).lo0 + rh_t_.x * RH_BX + (int)threadIdx.x; const int j = (b).lo1 + rh_t_.y * RH_BY + (int)threadIdx.y
 #define RH_KZ rh_t_.z      /* grid.z index of a pointwise 3-D kernel (after RH_IJ) */
 

@@ -703,7 +703,7 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
     __shared__ double lds[2 * SET + NINV * NT];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
     double *inv = lds + 2 * SET + tid;
-    const RhTile rh_t_ = rh_tile();
+    const RhTile rh_t_ = rh_tile_patch<8, 4>();          // one block per CU (109 KB LDS): 32 resident per XCD
     const int i0 = un.lo0 + rh_t_.x * RT_BX, j0 = un.lo1 + rh_t_.y * RT_BY;
     const int i = i0 + tx, j = j0 + ty;
     const bool au = inb2(xb, i, j), av = inb2(yb, i, j);
