@@ -422,41 +422,72 @@ __device__ __forceinline__ double hmean_inv(double a, double b)    // :91-96: cf
     if (cff > eps) { const double cff1 = 1.0 / (b + a); return cff * cff1; }
     return 0.0;
 }
+template <class TR, class TZ, class TP, class TH>
+__device__ __forceinline__ double prsgrd_point(const TR &rho, const TZ &z_r, const TP &P, const TH &Hz, int i, int j, int k, int di, int dj,
+                                               double m1, double m0, double mp, double metric, double HalfGRho)
+{   // one momentum point of :103-149 (di = 1) or :152-196 (dj = 1): four-point window along the direction of the gradient
+    const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
+    const double r2 = rho(i - 2 * di, j - 2 * dj, k), r1 = rho(i - di, j - dj, k), r0 = rho(i, j, k), rp = rho(i + di, j + dj, k);
+    const double z2 = z_r(i - 2 * di, j - 2 * dj, k), z1 = z_r(i - di, j - dj, k), z0 = z_r(i, j, k), zp = z_r(i + di, j + dj, k);
+    const double FC1 = (r1 - r2) * m1, FC0 = (r0 - r1) * m0, FCp = (rp - r0) * mp;
+    const double ax1 = (z1 - z2) * m1, ax0 = (z0 - z1) * m0, axp = (zp - z0) * mp;
+    const double dZx0 = hmean_inv(ax0, axp), dZx1 = hmean_inv(ax1, ax0);
+    const double dRx0 = hmean_inv(FCp, FC0), dRx1 = hmean_inv(FC0, FC1);
+    const double rho_diff = r0 - r1 - OneTwelfth * (dRx0 + dRx1);
+    const double z_r_diff = z0 - z1 - OneTwelfth * (dZx0 + dZx1);
+    const double Hz_avg = 0.5 * (Hz(i, j, k) + Hz(i - di, j - dj, k));
+    return metric * Hz_avg * (P(i - di, j - dj, k) - P(i, j, k) - HalfGRho *
+        ((r0 + r1) * (z0 - z1) - OneFifth * ((dRx0 - dRx1) * z_r_diff - (dZx0 - dZx1) * rho_diff)));
+}
 __global__ void k_prsgrd_uv(B3 ub, B3 vb, B3 un, A4 ru, A4 rv, A4 pn, A4 pm, A4 rho, A4 P, A4 Hz, A4 z_r, A4 msku, A4 mskv,
                             int nrhs, double HalfGRho)
 {
     RH_IJ(un);
     const int k = un.lo2 + RH_KZ;
-    const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
     if (inb2(ub, i, j)) {
-        const double r2 = rho(i - 2, j, k), r1 = rho(i - 1, j, k), r0 = rho(i, j, k), rp = rho(i + 1, j, k);
-        const double z2 = z_r(i - 2, j, k), z1 = z_r(i - 1, j, k), z0 = z_r(i, j, k), zp = z_r(i + 1, j, k);
-        const double m1 = msku(i - 1, j, 0), m0 = msku(i, j, 0), mp = msku(i + 1, j, 0);
-        const double FC1 = (r1 - r2) * m1, FC0 = (r0 - r1) * m0, FCp = (rp - r0) * mp;
-        const double ax1 = (z1 - z2) * m1, ax0 = (z0 - z1) * m0, axp = (zp - z0) * mp;
-        const double dZx0 = hmean_inv(ax0, axp), dZx1 = hmean_inv(ax1, ax0);
-        const double dRx0 = hmean_inv(FCp, FC0), dRx1 = hmean_inv(FC0, FC1);
-        const double rho_diff = r0 - r1 - OneTwelfth * (dRx0 + dRx1);
-        const double z_r_diff = z0 - z1 - OneTwelfth * (dZx0 + dZx1);
-        const double Hz_avg = 0.5 * (Hz(i, j, k) + Hz(i - 1, j, k));
         const double on_u = 2.0 / (pn(i - 1, j, 0) + pn(i, j, 0));
-        ru(i, j, k, nrhs) = on_u * Hz_avg * (P(i - 1, j, k) - P(i, j, k) - HalfGRho *
-            ((r0 + r1) * (z0 - z1) - OneFifth * ((dRx0 - dRx1) * z_r_diff - (dZx0 - dZx1) * rho_diff)));
+        ru(i, j, k, nrhs) = prsgrd_point(rho, z_r, P, Hz, i, j, k, 1, 0, msku(i - 1, j, 0), msku(i, j, 0), msku(i + 1, j, 0), on_u, HalfGRho);
     }
     if (inb2(vb, i, j)) {
-        const double r2 = rho(i, j - 2, k), r1 = rho(i, j - 1, k), r0 = rho(i, j, k), rp = rho(i, j + 1, k);
-        const double z2 = z_r(i, j - 2, k), z1 = z_r(i, j - 1, k), z0 = z_r(i, j, k), zp = z_r(i, j + 1, k);
-        const double m1 = mskv(i, j - 1, 0), m0 = mskv(i, j, 0), mp = mskv(i, j + 1, 0);
-        const double FC1 = (r1 - r2) * m1, FC0 = (r0 - r1) * m0, FCp = (rp - r0) * mp;
-        const double ax1 = (z1 - z2) * m1, ax0 = (z0 - z1) * m0, axp = (zp - z0) * mp;
-        const double dZx0 = hmean_inv(ax0, axp), dZx1 = hmean_inv(ax1, ax0);
-        const double dRx0 = hmean_inv(FCp, FC0), dRx1 = hmean_inv(FC0, FC1);
-        const double rho_diff = r0 - r1 - OneTwelfth * (dRx0 + dRx1);
-        const double z_r_diff = z0 - z1 - OneTwelfth * (dZx0 + dZx1);
-        const double Hz_avg = 0.5 * (Hz(i, j, k) + Hz(i, j - 1, k));
         const double om_v = 2.0 / (pm(i, j - 1, 0) + pm(i, j, 0));
-        rv(i, j, k, nrhs) = om_v * Hz_avg * (P(i, j - 1, k) - P(i, j, k) - HalfGRho *
-            ((r0 + r1) * (z0 - z1) - OneFifth * ((dRx0 - dRx1) * z_r_diff - (dZx0 - dZx1) * rho_diff)));
+        rv(i, j, k, nrhs) = prsgrd_point(rho, z_r, P, Hz, i, j, k, 0, 1, mskv(i, j - 1, 0), mskv(i, j, 0), mskv(i, j + 1, 0), om_v, HalfGRho);
+    }
+}
+// LDS-tiled form: the direct form asks the fabric for 13 doubles per cell where 4 are distinct (profiles/r1_v3_traffic.json).  A
+// block walks the column of one 64 x 8 tile: per level it stages rho, z_r (halo 2) and P, Hz (halo 1) in LDS (double-buffered on
+// the parity of k, the next level's values already on their way), and every stencil neighbour is read from LDS.
+__global__ void __launch_bounds__(RT_BX * RT_BY)
+k_prsgrd_uv_tiled(B3 ub, B3 vb, B3 un, A4 ru, A4 rv, A4 pn, A4 pm, A4 rho, A4 P, A4 Hz, A4 z_r, A4 msku, A4 mskv, int nrhs, double HalfGRho)
+{
+    typedef Tile<2, 2> T2; typedef Tile<1, 1> T1;
+    constexpr int SET = 2 * T2::SIZE + 2 * T1::SIZE;
+    __shared__ double lds[2 * SET];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const RhTile rh_t_ = rh_tile();
+    const int i0 = un.lo0 + rh_t_.x * RT_BX, j0 = un.lo1 + rh_t_.y * RT_BY;
+    const int i = i0 + tx, j = j0 + ty;
+    const bool au = inb2(ub, i, j), av = inb2(vb, i, j);
+    double on_u = 0.0, om_v = 0.0, mu1 = 0.0, mu0 = 0.0, mup = 0.0, mv1 = 0.0, mv0 = 0.0, mvp = 0.0;
+    if (au) { on_u = 2.0 / (pn(i - 1, j, 0) + pn(i, j, 0)); mu1 = msku(i - 1, j, 0); mu0 = msku(i, j, 0); mup = msku(i + 1, j, 0); }
+    if (av) { om_v = 2.0 / (pm(i, j - 1, 0) + pm(i, j, 0)); mv1 = mskv(i, j - 1, 0); mv0 = mskv(i, j, 0); mvp = mskv(i, j + 1, 0); }
+    const HaloCell hr = halo_cell<2, 2>(rho, i0, j0, tx, ty), hz = halo_cell<2, 2>(z_r, i0, j0, tx, ty),
+                   hp = halo_cell<1, 1>(P, i0, j0, tx, ty), hh = halo_cell<1, 1>(Hz, i0, j0, tx, ty);
+    const int k0 = un.lo2, k1 = un.hi2;
+    double r0 = ld_in(rho, i, j, k0), z0 = ld_in(z_r, i, j, k0), p0 = ld_in(P, i, j, k0), h0 = ld_in(Hz, i, j, k0);
+    double rh = halo_ld(rho, hr, k0), zh = halo_ld(z_r, hz, k0), ph = halo_ld(P, hp, k0), hhv = halo_ld(Hz, hh, k0);
+    for (int k = k0; k <= k1; k++) {
+        double *set = lds + ((k - k0) & 1) * SET;
+        double *sr = set, *sz = sr + T2::SIZE, *sp = sz + T2::SIZE, *sh = sp + T1::SIZE;
+        tile_put<2, 2>(sr, tx, ty, r0, hr, rh); tile_put<2, 2>(sz, tx, ty, z0, hz, zh);
+        tile_put<1, 1>(sp, tx, ty, p0, hp, ph); tile_put<1, 1>(sh, tx, ty, h0, hh, hhv);
+        if (k + 1 <= k1) {
+            r0 = ld_in(rho, i, j, k + 1); z0 = ld_in(z_r, i, j, k + 1); p0 = ld_in(P, i, j, k + 1); h0 = ld_in(Hz, i, j, k + 1);
+            rh = halo_ld(rho, hr, k + 1); zh = halo_ld(z_r, hz, k + 1); ph = halo_ld(P, hp, k + 1); hhv = halo_ld(Hz, hh, k + 1);
+        }
+        __syncthreads();
+        const TView<2, 2> vr{sr, i0, j0}, vz{sz, i0, j0}; const TView<1, 1> vp{sp, i0, j0}, vh{sh, i0, j0};
+        if (au) ru(i, j, k, nrhs) = prsgrd_point(vr, vz, vp, vh, i, j, k, 1, 0, mu1, mu0, mup, on_u, HalfGRho);
+        if (av) rv(i, j, k, nrhs) = prsgrd_point(vr, vz, vp, vh, i, j, k, 0, 1, mv1, mv0, mvp, om_v, HalfGRho);
     }
 }
 extern "C" int rh_prsgrd(rh_ctx *c, rh_box phi_bx, rh_box utbx, rh_box vtbx, rh_array4 ru, rh_array4 rv, rh_array4 pn, rh_array4 pm,
@@ -478,8 +509,13 @@ extern "C" int rh_prsgrd(rh_ctx *c, rh_box phi_bx, rh_box utbx, rh_box vtbx, rh_
     RH_NEED(ru, utbx); RH_NEED(rv, vtbx);
     if (nrhs < 0 || nrhs >= ru.ncomp || nrhs >= rv.ncomp) return rh_fail("rh_prsgrd: nrhs out of range");
     const rh_box un = bx_union(utbx, vtbx);
-    k_prsgrd_uv<<<grid3(un), rh_block(), 0, c->stream>>>(mkB(utbx), mkB(vtbx), mkB(un), mkA(ru), mkA(rv), mkA(pn), mkA(pm), mkA(rho),
-        mkA(P), mkA(Hz), mkA(z_r), mkA(msku), mkA(mskv), nrhs, HalfGRho);
+    if (c->unfused)
+        k_prsgrd_uv<<<grid3(un), rh_block(), 0, c->stream>>>(mkB(utbx), mkB(vtbx), mkB(un), mkA(ru), mkA(rv), mkA(pn), mkA(pm), mkA(rho),
+            mkA(P), mkA(Hz), mkA(z_r), mkA(msku), mkA(mskv), nrhs, HalfGRho);
+    else {
+        k_prsgrd_uv_tiled<<<rt_grid(un), rt_block(), 0, c->stream>>>(mkB(utbx), mkB(vtbx), mkB(un), mkA(ru), mkA(rv), mkA(pn), mkA(pm), mkA(rho),
+            mkA(P), mkA(Hz), mkA(z_r), mkA(msku), mkA(mskv), nrhs, HalfGRho);
+    }
     RH_LAUNCH_CHECK(); return 0;
 }
 
@@ -883,6 +919,93 @@ __global__ void k_uv3dmix(B3 xb, B3 yb, B3 un, A4 u, A4 v, A4 uold, A4 vold, A4 
         rvfrc(i, j, 0) = frc;
     }
 }
+// LDS-tiled, k-marching form of k_uv3dmix (same arithmetic).  The direct form evaluates every stress twice and asks the fabric
+// for 15 doubles per cell where 5 are distinct (profiles/r1_v3_traffic.json).  Here a block stages uold, vold, Hz of one level
+// (64 x 8 footprint, halo 1); each thread evaluates the stresses of ITS rho point and ITS psi point once and parks them in LDS;
+// the u and v points combine their own values with the neighbour's.  Blocks overlap by one column and one row (stride 63 x 7,
+// as in k2d_uvbar), so no thread computes a halo stress.  Input and stress tiles are double-buffered on the parity of k and the
+// update runs one level behind the stresses: one barrier per level.
+#define M3_SX (RT_BX - 1)
+#define M3_SY (RT_BY - 1)
+__global__ void __launch_bounds__(RT_BX * RT_BY)
+k_uv3dmix_tiled(B3 xb, B3 yb, B3 un, A4 u, A4 v, A4 uold, A4 vold, A4 rufrc, A4 rvfrc, A4 visc2_p, A4 visc2_r, A4 Hz,
+                A4 pm, A4 pn, A4 mskp, int N, double dt)
+{
+    typedef Tile<1, 1> T1; typedef TView<1, 1> V1;
+    constexpr int NT = RT_BX * RT_BY, SET = 3 * T1::SIZE, FSET = 4 * NT;
+    __shared__ double lds[2 * SET + 2 * FSET];
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
+    const RhTile rh_t_ = rh_tile();
+    const int i0 = un.lo0 - 1 + rh_t_.x * M3_SX, j0 = un.lo1 - 1 + rh_t_.y * M3_SY;
+    const int i = i0 + tx, j = j0 + ty;
+    // rho points un.lo-1 .. un.hi and psi points un.lo .. un.hi+1 carry a stress some velocity point needs
+    const bool ar = i >= un.lo0 - 1 && i <= un.hi0 && j >= un.lo1 - 1 && j <= un.hi1;
+    const bool ap = i >= un.lo0 && i <= un.hi0 + 1 && j >= un.lo1 && j <= un.hi1 + 1;
+    const bool au = tx >= 1 && ty <= RT_BY - 2 && inb2(xb, i, j), av = tx <= RT_BX - 2 && ty >= 1 && inb2(yb, i, j);
+    MixR r; MixP p; memset(&r, 0, sizeof r); memset(&p, 0, sizeof p);
+    double fr_x = 0.0, fr_e = 0.0, fp_e = 0.0, fp_x = 0.0;
+    if (ar) { r = mix_r_metrics(pm, pn, visc2_r, i, j); fr_x = r.on_r * r.on_r * r.visc; fr_e = r.om_r * r.om_r * r.visc; }
+    if (ap) { p = mix_p_metrics(pm, pn, visc2_p, mskp, i, j); fp_e = p.om_p * p.om_p * p.visc; fp_x = p.on_p * p.on_p * p.visc; }
+    double cu = 0.0, hspn_u = 0.0, hspm_u = 0.0, frcu = 0.0, cv = 0.0, hspn_v = 0.0, hspm_v = 0.0, frcv = 0.0;
+    if (au) {
+        const double spm = pm(i - 1, j, 0) + pm(i, j, 0), spn = pn(i - 1, j, 0) + pn(i, j, 0);
+        cu = dt * 0.25 * spm * spn; hspn_u = 0.5 * spn; hspm_u = 0.5 * spm; frcu = rufrc(i, j, 0);
+    }
+    if (av) {
+        const double spm = pm(i, j, 0) + pm(i, j - 1, 0), spn = pn(i, j, 0) + pn(i, j - 1, 0);
+        const double spn2 = pn(i, j - 1, 0) + pn(i, j, 0), spm2 = pm(i, j - 1, 0) + pm(i, j, 0);
+        cv = dt * 0.25 * spm * spn; hspn_v = 0.5 * spn2; hspm_v = 0.5 * spm2; frcv = rvfrc(i, j, 0);
+    }
+    const HaloCell hu = halo_cell<1, 1>(uold, i0, j0, tx, ty), hv = halo_cell<1, 1>(vold, i0, j0, tx, ty), hh = halo_cell<1, 1>(Hz, i0, j0, tx, ty);
+    double u0 = ld_in(uold, i, j, 0), v0 = ld_in(vold, i, j, 0), hz = ld_in(Hz, i, j, 0);
+    double uh = halo_ld(uold, hu, 0), vh = halo_ld(vold, hv, 0), hzh = halo_ld(Hz, hh, 0);
+    double un_k = au ? u(i, j, 0) : 0.0, vn_k = av ? v(i, j, 0) : 0.0;        // the fields being updated, level of the pending update
+    for (int k = 0; k <= N + 1; k++) {
+        double *set = lds + (k & 1) * SET, *fl = lds + 2 * SET + (k & 1) * FSET + tid;
+        const double *flp = lds + 2 * SET + ((k + 1) & 1) * FSET + tid;       // stresses of level k-1
+        double u0_n = 0.0, v0_n = 0.0, hz_n = 0.0, uh_n = 0.0, vh_n = 0.0, hzh_n = 0.0, un_n = 0.0, vn_n = 0.0;
+        if (k <= N) {
+            tile_put<1, 1>(set, tx, ty, u0, hu, uh); tile_put<1, 1>(set + T1::SIZE, tx, ty, v0, hv, vh); tile_put<1, 1>(set + 2 * T1::SIZE, tx, ty, hz, hh, hzh);
+            if (k + 1 <= N) {
+                u0_n = ld_in(uold, i, j, k + 1); v0_n = ld_in(vold, i, j, k + 1); hz_n = ld_in(Hz, i, j, k + 1);
+                uh_n = halo_ld(uold, hu, k + 1); vh_n = halo_ld(vold, hv, k + 1); hzh_n = halo_ld(Hz, hh, k + 1);
+            }
+            if (k >= 1) { un_n = au ? u(i, j, k) : 0.0; vn_n = av ? v(i, j, k) : 0.0; }
+        }
+        __syncthreads();
+        if (k <= N) {
+            const V1 tu{set, i0, j0}, tv{set + T1::SIZE, i0, j0}, th{set + 2 * T1::SIZE, i0, j0};
+            double cr = 0.0, cp = 0.0;
+            if (ar) cr = mix_r_cff(r, th, tu, tv, i, j, 0);
+            if (ap) cp = mix_p_cff(p, th, tu, tv, i, j, 0);
+            fl[0 * NT] = fr_x * cr; fl[1 * NT] = fr_e * cr; fl[2 * NT] = fp_e * cp; fl[3 * NT] = fp_x * cp;     // UFx, VFe, UFe, VFx
+        }
+        if (k >= 1) {
+            const int km = k - 1;
+            if (au) {
+                const double UFx0 = flp[0 * NT], UFx1 = flp[0 * NT - 1], UFe0 = flp[2 * NT], UFe1 = flp[2 * NT + RT_BX];
+                const double cff1 = hspn_u * (UFx0 - UFx1);
+                const double cff2 = hspm_u * (UFe1 - UFe0);
+                const double cff3 = cu * (cff1 + cff2);
+                u(i, j, km) = un_k + cff3;
+                frcu += cff1 + cff2;
+            }
+            if (av) {
+                const double VFe0 = flp[1 * NT], VFe1 = flp[1 * NT - RT_BX], VFx0 = flp[3 * NT], VFx1 = flp[3 * NT + 1];
+                const double cff1 = hspn_v * (VFx1 - VFx0);
+                const double cff2 = hspm_v * (VFe0 - VFe1);
+                const double cff3 = cv * (cff1 - cff2);
+                v(i, j, km) = vn_k + cff3;
+                frcv += cff1 - cff2;
+            }
+        }
+        if (k >= 1) { un_k = un_n; vn_k = vn_n; }
+        u0 = u0_n; v0 = v0_n; hz = hz_n; uh = uh_n; vh = vh_n; hzh = hzh_n;
+    }
+    if (au) rufrc(i, j, 0) = frcu;
+    if (av) rvfrc(i, j, 0) = frcv;
+}
+
 extern "C" int rh_uv3dmix(rh_ctx *c, rh_box xbx, rh_box ybx, rh_array4 u, rh_array4 v, rh_array4 uold, rh_array4 vold,
                           rh_array4 rufrc, rh_array4 rvfrc, rh_array4 visc2_p, rh_array4 visc2_r, rh_array4 Hz, rh_array4 pm,
                           rh_array4 pn, rh_array4 mskp, int nrhs, int nnew, double dt)
@@ -893,9 +1016,16 @@ extern "C" int rh_uv3dmix(rh_ctx *c, rh_box xbx, rh_box ybx, rh_array4 u, rh_arr
     if (xbx.lo[2] != 0 || ybx.lo[2] != 0) return rh_fail("rh_uv3dmix: boxes must start at k = 0");
     const rh_box un = bx_union(xbx, ybx);
     { rh_box q = bx_grow(un, 1, 1, 0); RH_NEED(uold, q); RH_NEED(vold, q); RH_NEED(Hz, q);
-      rh_box q2 = bx_slab(q, 2, 0); RH_NEED(pm, q2); RH_NEED(pn, q2); RH_NEED(visc2_r, q2); RH_NEED(visc2_p, q2); RH_NEED(mskp, q2); }
+      rh_box q2 = bx_slab(q, 2, 0); RH_NEED(visc2_r, q2); RH_NEED(visc2_p, q2); RH_NEED(mskp, q2);
+      q2 = bx_slab(bx_grow(un, 2, 2, 0), 2, 0); RH_NEED(pm, q2); RH_NEED(pn, q2); }
     RH_NEED(u, xbx); RH_NEED(v, ybx); RH_NEED(rufrc, bx_slab(xbx, 2, 0)); RH_NEED(rvfrc, bx_slab(ybx, 2, 0));
-    k_uv3dmix<<<grid2(un), rh_block(), 0, c->stream>>>(mkB(xbx), mkB(ybx), mkB(un), mkA(u), mkA(v), mkA(uold), mkA(vold), mkA(rufrc), mkA(rvfrc),
-        mkA(visc2_p), mkA(visc2_r), mkA(Hz), mkA(pm), mkA(pn), mkA(mskp), N, dt);
+    if (c->unfused)
+        k_uv3dmix<<<grid2(un), rh_block(), 0, c->stream>>>(mkB(xbx), mkB(ybx), mkB(un), mkA(u), mkA(v), mkA(uold), mkA(vold), mkA(rufrc), mkA(rvfrc),
+            mkA(visc2_p), mkA(visc2_r), mkA(Hz), mkA(pm), mkA(pn), mkA(mskp), N, dt);
+    else {
+        const dim3 grid((un.hi[0] - un.lo[0] + 1 + M3_SX) / M3_SX, (un.hi[1] - un.lo[1] + 1 + M3_SY) / M3_SY, 1);
+        k_uv3dmix_tiled<<<grid, rt_block(), 0, c->stream>>>(mkB(xbx), mkB(ybx), mkB(un), mkA(u), mkA(v), mkA(uold), mkA(vold), mkA(rufrc), mkA(rvfrc),
+            mkA(visc2_p), mkA(visc2_r), mkA(Hz), mkA(pm), mkA(pn), mkA(mskp), N, dt);
+    }
     RH_LAUNCH_CHECK(); return 0;
 }
