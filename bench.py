@@ -21,25 +21,55 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 
-# Algorithmic bytes per cell per launch of each kernel group (8 B x distinct 3-D field components
-# read + written, each counted once; 2-D arrays ignored).
+# Algorithmic doubles per cell per launch of each kernel group (distinct 3-D field components read + distinct
+# 3-D field components written, each counted once; 2-D arrays, scratch, halo and cache re-reads are NOT counted).  A fused group
+# counts the union of its members.
 ALGO_DOUBLES = {
-    "rhs_t_3d": 6 + 1,             # sstore, t, Huon, Hvom, Hz, W -> t
-    "prestep_t": 7 + 2,            # told, tnew, Hz, Huon, Hvom, W(k), (W k+1 shared) -> sstore, tnew
-    "rhs_uv_3d": 8 + 2,            # uold, vold, ru, rv, Huon, Hvom, W, Hz -> ru, rv
+    "prestep_t3": 10 + 6,          # told x3, tnew x3, Hz, Huon, Hvom, W -> sstore x3, tnew x3   (3 tracers in one launch)
+    "rhs_t3": 10 + 3,              # sstore x3, t x3, Huon, Hvom, Hz, W -> t x3
+    "rhs_uv_3d": 8 + 2,            # uold, vold, ru, rv, Huon, Hvom, W, Hz -> ru, rv          (coriolis folded in)
     "uv3dmix": 5 + 2,              # uold, vold, Hz, u, v -> u, v
-    "vert_visc_3d": 3 + 1,         # phi, Hz, Akv -> phi
-    "vert_mean_3d": 2 + 1,
-    "update_massflux_3d": 3 + 2,   # phi, Hz, Hphi -> Hphi (+phi at boundary faces only)
-    "prsgrd": 4 + 2,               # rho, z_r, Hz, (z_w top only) + P scratch -> ru, rv
+    "uv_corrector": 4 + 1,         # u, ru, Hz, Akv -> u     (AB3 + vert_visc_3d + vert_mean_3d; one launch per velocity)
+    "vert_visc_3d": 3 + 1,         # phi, Hz, Akt -> phi
+    "update_massflux_3d": 3 + 1,   # phi, Hphi, Hz -> Hphi (+ phi on boundary faces only)
+    "prsgrd": 4 + 2,               # rho, z_r, Hz, (z_w top level) -> ru, rv   (P is scratch: not counted)
     "rho_eos": 4 + 2,              # T, S, Hz, z_r -> rho, bvf
-    "omega": 2 + 1,
-    "t3dmix": 3 + 1,
-    "prestep_uv": 3 + 2,
-    "uv_ab3": 5 + 2,
+    "omega": 3 + 1,                # Huon, Hvom, z_w -> W
+    "prestep_uv": 4 + 3,           # vel_old, Hz, rvel x2 -> vel, rvel x2
     "stretch_transform": 0 + 3,
+    "vmix": 0 + 4,
     "massflux_old": 3 + 2,
 }
+# kernel(s) behind each group in the rocprofv3 output (profiles/*_traffic.json keys start with these)
+GROUP_KERNELS = {
+    "prestep_t3": ["k_tracers_tiled<0"], "rhs_t3": ["k_tracers_tiled<1"], "rhs_uv_3d": ["k_rhs_uv_tiled"], "uv3dmix": ["k_uv3dmix_tiled"],
+    "uv_corrector": ["k_column_solver<1, 0, 1", "k_column_solver<0, 1, 1"], "vert_visc_3d": ["k_column_solver<0, 0, 0"],
+    "update_massflux_3d": ["k_massflux_lds"], "prsgrd": ["k_prsgrd_P", "k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos"], "omega": ["k_omega_lds"],
+    "prestep_uv": ["k_prestep_uv"], "stretch_transform": ["k_stretch"], "vmix": ["k_vmix"], "massflux_old": ["k_massflux_old"],
+}
+
+
+def pmc_traffic(group, cells):
+    """HBM-side bytes per launch of the group's kernel from the committed PMC passes (profiles/r1_traffic.json, collected with
+    tools/pmc_traffic.sh on this same workload and calibrated as MI355X_MICROARCH.md prescribes); None if absent or another size."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    if not os.path.exists(path) or group not in GROUP_KERNELS:
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    if t.get("cells") != cells:
+        return None
+    tot = 0.0; n = 0
+    for pre in GROUP_KERNELS[group]:
+        ks = [v for k, v in t["kernels"].items() if k.startswith(pre)]
+        if not ks:
+            return None
+        # several instantiations of one kernel (u / v): average them; several kernels in a group (prsgrd): add them
+        tot += sum(v["read_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks) / len(ks)
+        n += 1
+    if group == "uv_corrector":
+        tot /= 2.0                  # its two entries are the two instantiations of one per-velocity launch
+    return tot
 
 
 def parse():
@@ -148,7 +178,7 @@ def main():
         bytes_launch = ALGO_DOUBLES[dom] * 8 * cells_per_gpu
         ach = bytes_launch / (avg_ms * 1e-3) / 1e9
         roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_launch,
+                "traffic": pmc_traffic(dom, cells_per_gpu), "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_launch,
                 "share_of_step": leaf[dom]["ms"] / nprof / (el / a.steps * 1e3)}
     if rank == 0:
         out = {"metric": "3D baroclinic cell-updates/s", "value": cells_per_gpu * world * a.steps / el, "unit": "cell-updates/s",

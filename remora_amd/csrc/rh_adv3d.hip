@@ -225,13 +225,13 @@ k_column_solver(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm
         AK_0 = 0.5 * (second(a1, a1x) + a1);
         phi_m = start(phi(ic, j, 0), FULL ? rphi(ic, j, 0) : 0.0, hs);
     }
-    double CFp = 0.0, DCp = 0.0;
+    double CFp = 0.0, DCp = 0.0, oHz_m = 1.0 / Hzk_m;
     auto fwd = [&](int k, const ColLvl &c) {              // level k of the elimination (all lanes: `second` shuffles)
         const double hs = second(c.H, c.Hx) + c.H;
         const double Hzk_0 = 0.5 * hs;
         const double AK_p = 0.5 * (second(c.A, c.Ax) + c.A);
         const double phi_0 = start(c.P, c.R, hs);
-        const double oHzkm1 = 1.0 / Hzk_m;
+        const double oHzkm1 = oHz_m;                      // 1 / Hzk(k-1): the previous level's quotient, same operands, same bits
         const double oHz = 1.0 / Hzk_0;
         const double FC = sixth * Hzk_m - dt * AK_m / Hzk_m;
         double CF = sixth * Hzk_0 - dt * AK_p / Hzk_0;
@@ -243,7 +243,7 @@ k_column_solver(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm
         // without the AB3 term phi_0 IS the loaded register: carried into the next level as phi_m it would outlive the ring slot,
         // and the copies that keeps alive make every loop iteration start by draining the ring.  An opaque move cuts the tie.
         double carry = phi_0; asm volatile("" : "+v"(carry));
-        CFp = CF; DCp = DC; Hzk_m = Hzk_0; AK_m = AK_0; AK_0 = AK_p; phi_m = carry;
+        CFp = CF; DCp = DC; Hzk_m = Hzk_0; AK_m = AK_0; AK_0 = AK_p; phi_m = carry; oHz_m = oHz;
     };
     ColLvl ring[D];
 #pragma unroll
@@ -332,7 +332,6 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     const size_t lds_bytes = sizeof(double) * 2 * (size_t)(N + 2) * 64;
     *applied = 0;
     if (c->unfused || lds_bytes > 64 * 1024) return 0;
-    TScope t(c, "uv_corrector");
     const int iic = istep, ntfirst = 0;
     double cab;
     if (iic == ntfirst) cab = 0.25 * dt; else if (iic == ntfirst + 1) cab = 0.25 * dt * 3.0 / 2.0; else cab = 0.25 * dt * 23.0 / 12.0;
@@ -345,9 +344,11 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     RH_NEED(s->pm, bx_slab(xs, 2, 0)); RH_NEED(s->pn, bx_slab(xs, 2, 0)); RH_NEED(s->pm, bx_slab(ys, 2, 0)); RH_NEED(s->pn, bx_slab(ys, 2, 0));
     RH_NEED(s->DU_avg1, bx_slab(xbx, 2, 0)); RH_NEED(s->DV_avg1, bx_slab(ybx, 2, 0)); RH_NEED(s->msku, bx_slab(xbx, 2, 0)); RH_NEED(s->mskv, bx_slab(ybx, 2, 0));
     const dim3 gx((xbx.hi[0] - xbx.lo[0] + 64) / 64, xbx.hi[1] - xbx.lo[1] + 1, 1), gy((ybx.hi[0] - ybx.lo[0] + 64) / 64, ybx.hi[1] - ybx.lo[1] + 1, 1);
+    { TScope t(c, "uv_corrector");
     k_column_solver<1, 0, 1, VV_D_V><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn),
         mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab);
-    RH_LAUNCH_CHECK();
+    RH_LAUNCH_CHECK(); }
+    TScope t(c, "uv_corrector");
     k_column_solver<0, 1, 1, VV_D_V><<<gy, 64, lds_bytes, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm),
         mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab);
     RH_LAUNCH_CHECK();
