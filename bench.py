@@ -4,7 +4,7 @@
 A "step" is one full REMORA::Advance (setup_step + the barotropic sub-steps + advance_3d_ml, ghost exchange included)
 of the DoubleGyre physics (Exec/DoubleGyre, Tests/test_files/DoubleGyre/DoubleGyre.i) on a 2048 x 2048 x 50 block per GPU
 (BASELINE.json configs[3]).  With N > 1 the domain is 2048 x (2048 N) x 50, split into N j-slabs
-(weak scaling), and every FillBoundary becomes an RCCL send/recv with the two slab neighbours.
+(weak scaling; --grid PXxPY picks another i-j process grid), and every FillBoundary becomes RCCL send/recv with the neighbours.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     -- the dominant kernel group of the step, measured live with HIP events on the library's stream
@@ -80,20 +80,23 @@ def parse():
     ap.add_argument("--nx", type=int, default=2048)
     ap.add_argument("--ny", type=int, default=2048, help="cells in j PER GPU")
     ap.add_argument("--nz", type=int, default=50)
+    ap.add_argument("--grid", type=str, default="", help="process grid PXxPY (PX * PY = --gpus); default 1xN = j-slabs, every rank keeps full 512-B-coalesced i rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="192x192x50x2", help="nx x ny x nz x steps of the CPU-oracle sample")
     return ap.parse_args()
 
 
-def bench_case(nx, ny_per_gpu, nz, ngpu):
+def bench_case(nx_per_gpu, ny_per_gpu, nz, px, py=None):
     from remora_amd import cases
+    if py is None:
+        px, py = 1, px
     c = cases.get("DoubleGyre")
     base = c["ncell"]
-    ny = ny_per_gpu * ngpu
-    # same physical x extent; y extent grows with the GPU count so dy (and the work per GPU) is fixed
-    c["prob_hi"] = (c["prob_hi"][0], c["prob_hi"][1] * ngpu, c["prob_hi"][2])
+    nx, ny = nx_per_gpu * px, ny_per_gpu * py
+    # the physical extent grows with the process grid so dx, dy (and the work per GPU) are fixed
+    c["prob_hi"] = (c["prob_hi"][0] * px, c["prob_hi"][1] * py, c["prob_hi"][2])
     c["ncell"] = (nx, ny, nz)
-    c["fixed_dt"] = float(c["fixed_dt"] * min(base[0] / nx, base[1] / ny_per_gpu))    # CFL scaling
+    c["fixed_dt"] = float(c["fixed_dt"] * min(base[0] / nx_per_gpu, base[1] / ny_per_gpu))    # CFL scaling
     return c
 
 
@@ -129,10 +132,14 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
 
     from remora_amd.model import REMORA
-    case = bench_case(a.nx, a.ny, a.nz, world)
+    px, py = (int(x) for x in a.grid.split("x")) if a.grid else (1, world)
+    if px * py != world:
+        raise SystemExit(f"--grid {a.grid} does not match {world} ranks")
+    rx, ry = rank % px, rank // px
+    case = bench_case(a.nx, a.ny, a.nz, px, py)
     nx, ny, nz = case["ncell"]
-    box = ((0, rank * a.ny, 0), (nx - 1, (rank + 1) * a.ny - 1, nz - 1))
-    rem = REMORA(case, device=f"cuda:{local}", box=box, nranks=(1, world), rank_xy=(0, rank))
+    box = ((rx * a.nx, ry * a.ny, 0), ((rx + 1) * a.nx - 1, (ry + 1) * a.ny - 1, nz - 1))
+    rem = REMORA(case, device=f"cuda:{local}", box=box, nranks=(px, py), rank_xy=(rx, ry))
     if world > 1:
         rem.comm_init(dist)
     rem.InitData()
@@ -169,7 +176,7 @@ def main():
     rep = rem.timing_report()
     rem.timing(False)
 
-    cells_per_gpu = nx * a.ny * nz
+    cells_per_gpu = a.nx * a.ny * nz
     roof = None
     leaf = {k: v for k, v in rep.items() if k in ALGO_DOUBLES}
     if leaf:
@@ -184,10 +191,10 @@ def main():
         out = {"metric": "3D baroclinic cell-updates/s", "value": cells_per_gpu * world * a.steps / el, "unit": "cell-updates/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": f"DoubleGyre physics, {nx}x{a.ny}x{nz} cells per GPU (domain {nx}x{ny}x{nz}), "
+               "config": {"workload": f"DoubleGyre physics, {a.nx}x{a.ny}x{nz} cells per GPU (domain {nx}x{ny}x{nz}), "
                                       f"dt {case['fixed_dt']:.3f} s, ndtfast {case['ndtfast']}, nfast {rem.nfast}, "
-                                      f"{'j-slab decomposition over RCCL' if world > 1 else 'single box'}",
-                          "parallelism": f"ij-decomp 1x{world}"},
+                                      f"{f'{px}x{py} i-j decomposition, ghost exchange over RCCL' if world > 1 else 'single box'}",
+                          "parallelism": f"ij-decomp {px}x{py}"},
                "finite": finite,
                "roofline": roof,
                "kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])},

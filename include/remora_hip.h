@@ -92,7 +92,8 @@ int  rh_comm_unique_id(void *id128);
 int  rh_comm_init(rh_ctx *ctx, const void *id128, int rank, int nranks);
 
 /* Transport hook: replaces the built-in RCCL send/recv pair of the ghost exchange, for hosts that own their communicator
- * (REMORA itself: AMReX ParallelDescriptor / GPU-aware MPI) and for tests (gloo).  Called once per exchange with DEVICE
+ * (REMORA itself: AMReX ParallelDescriptor / GPU-aware MPI) and for tests (gloo).  Called once per exchange phase (X: lower =
+ * left, upper = right neighbour; Y: lower / upper row neighbour; all arrays of one fill scope share the message) with DEVICE
  * buffers that are ready on `stream`: send n_lo doubles from send_lo to rank peer_lo and receive n_lo doubles from it into
  * recv_lo, likewise for the upper neighbour; a peer of -1 means no neighbour on that side.  The block sent to the lower
  * neighbour is what that neighbour receives from its upper one.  On return the receive buffers must be complete on `stream`.
@@ -105,16 +106,21 @@ int  rh_comm_set_exchange(rh_ctx *ctx, rh_exchange_fn fn, void *user, int rank, 
  * No counterpart in the reference. */
 int  rh_comm_selftest(rh_ctx *ctx, long n);
 
-/* Rows a rank exchanges with its j-neighbours for one array (host-only, needs no device): the geometry behind
- * rh_fill_boundary in a j-slab decomposition (nranks = {1, P}).  arr_lo/arr_hi = the array's grown box, ng = its ghost widths. */
+/* Ghost blocks a rank exchanges with its neighbours for one array (host-only, needs no device): the geometry behind
+ * rh_fill_boundary on an i-j process grid (rank = rank_xy[1] * nranks[0] + rank_xy[0]).  The exchange runs in two phases: X swaps
+ * ghost columns with the left / right neighbour over the valid rows, then Y swaps ghost rows with the lower / upper neighbour
+ * over the full width (ghost columns included), so corner blocks arrive in two hops and no diagonal message exists.
+ * arr_lo/arr_hi = the array's grown box, ng = its ghost widths.  rh_halo_plan_j describes phase Y.  rh_halo_plan_i describes
+ * phase X with the roles of i and j swapped: nrows = ghost columns, i_lo/i_hi = the ROW range of every column, *_j = first COLUMN. */
 typedef struct rh_halo_plan {
-    int peer_lo, peer_hi;        /* rank of the lower / upper j-neighbour, -1 = none (domain edge, not periodic) */
+    int peer_lo, peer_hi;        /* rank of the lower / upper neighbour, -1 = none (domain edge, not periodic; or a single rank) */
     int nrows;                   /* ghost rows exchanged on each side */
-    int i_lo, i_hi;              /* i-range of every row sent and received (x ghost columns only if x is periodic) */
+    int i_lo, i_hi;              /* i-range of every row sent and received (x ghost columns only where FillBoundary fills them) */
     int send_lo_j, send_hi_j;    /* first row of the block sent to the lower / to the upper neighbour */
     int recv_lo_j, recv_hi_j;    /* first row of the ghost block received from the lower / from the upper neighbour */
 } rh_halo_plan;
 int  rh_halo_plan_j(const rh_params *prm, const int arr_lo[3], const int arr_hi[3], const int ng[3], rh_halo_plan *out);
+int  rh_halo_plan_i(const rh_params *prm, const int arr_lo[3], const int arr_hi[3], const int ng[3], rh_halo_plan *out);
 
 /* ---- ghost cells ----------------------------------------------------------------------------------- */
 /* amrex::FabArray::FillBoundary(periodicity) for comps [icomp,icomp+ncomp): periodic wrap and, across ranks,

@@ -70,10 +70,11 @@ extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
     const double hc = -std::min(c->prm.prob_hi[2], -c->prm.tcline);                          // :51
     k_stretch<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(s->z_w), mkA(s->z_r), mkA(s->Hz), mkA(s->h), mkA(s->Zt_avg1), c->d_sc, nz, hc);
     RH_LAUNCH_CHECK();
+    BcScope xs(c);                                                                           // one message per neighbour for the three
     RH_TRY(halo_fill_boundary(c, mfv(c, s->z_w, 0, 0, 1), 0, 1));                            // :198-201
     RH_TRY(halo_fill_boundary(c, mfv(c, s->z_r, 0, 0, 0), 0, 1));
     RH_TRY(halo_fill_boundary(c, mfv(c, s->Hz, 0, 0, 0), 0, 1));
-    return 0;
+    return xs.end();
 }
 
 // ------------------------------------------------------------------------------------------------------------------

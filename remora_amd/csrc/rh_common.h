@@ -117,6 +117,8 @@ int rh_fail(const char *fmt, ...);
 struct BCRec3 { int lo[3], hi[3]; };
 void *bc_queue_new();
 void bc_queue_delete(void *q);
+void *halo_queue_new();
+void halo_queue_delete(void *q);
 
 // a view plus what AMReX keeps in the MultiFab: valid box, index type, ghost widths
 struct MFV { rh_array4 a; rh_box valid; int ix[3]; int ng[3]; };
@@ -143,9 +145,10 @@ struct rh_ctx {
     std::vector<std::vector<std::pair<hipEvent_t,hipEvent_t>>> tev;
     std::vector<hipEvent_t> evpool;
     void *bcq = nullptr; int bc_defer = 0;                     // queued physical-BC passes (rh_halo.hip)
+    void *haloq = nullptr;                                     // queued ghost exchanges of the same scope (rh_halo.hip)
     bool unfused = false;            // RH_UNFUSED=1: drivers call the per-leaf entry points instead of the fused kernels (A/B parity)
     bool poison = false;             // RH_POISON=1: NaN-fill the work space at the start of every step (stale-read detector)
-    ~rh_ctx() { if (bcq) bc_queue_delete(bcq); }
+    ~rh_ctx() { if (bcq) bc_queue_delete(bcq); if (haloq) halo_queue_delete(haloq); }
 };
 
 // timing scope: records events around a kernel group when enabled
@@ -161,7 +164,8 @@ MFV  mfv(const rh_ctx *c, const rh_array4 &a, int ix0, int ix1, int ix2);
 int  halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp);
 int  halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill);
 int  halo_fillpatch(rh_ctx *c, const MFV &m, const rh_array4 &msk, int bccomp, int icomp, int ncomp);
-// BC passes issued between bc_begin and the matching bc_end are queued and flushed as one launch per dependency level; only
+int  halo_flush(rh_ctx *c);
+// Ghost exchanges and BC passes issued between bc_begin and the matching bc_end are queued and flushed as one launch per dependency level; only
 // ghost-fill calls may sit inside such a scope (any other kernel on the same arrays would overtake the queued passes)
 void bc_begin(rh_ctx *c);
 int  bc_end(rh_ctx *c);

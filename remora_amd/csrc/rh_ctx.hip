@@ -276,20 +276,18 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     if (c->bx.lo[2] != c->dom.lo[2] || c->bx.hi[2] != c->dom.hi[2]) return bad("boxes must span the full vertical (main.cpp:21-23)");
     if (!bx_contains(c->dom, c->bx)) return bad("box outside domain");
     if (prm->ndtfast < 1) return bad("ndtfast < 1");
-    {
-        // j-slab decomposition: every rank owns the full i extent and a contiguous block of rows
-        const int P = prm->nranks[1] < 1 ? 1 : prm->nranks[1], r = prm->rank_xy[1];
-        if (prm->nranks[0] > 1) return bad("only j-slab decompositions (nranks = {1, P}) are implemented");
-        if (c->bx.lo[0] != c->dom.lo[0] || c->bx.hi[0] != c->dom.hi[0]) return bad("a rank must own the full i extent");
-        if (r < 0 || r >= P) return bad("rank_xy[1] outside the process grid");
-        if (P == 1 && (c->bx.lo[1] != c->dom.lo[1] || c->bx.hi[1] != c->dom.hi[1])) return bad("a single rank must own the whole domain");
+    // i-j decomposition: a tensor-product process grid; every rank owns one box, contiguous in i and j
+    for (int d = 0; d < 2; d++) {
+        const int P = prm->nranks[d] < 1 ? 1 : prm->nranks[d], r = prm->rank_xy[d];
+        if (r < 0 || r >= P) return bad("rank_xy outside the process grid");
+        if (P == 1 && (c->bx.lo[d] != c->dom.lo[d] || c->bx.hi[d] != c->dom.hi[d])) return bad("a direction with a single rank must be owned whole");
         if (P > 1) {
-            if ((r == 0) != (c->bx.lo[1] == c->dom.lo[1]) || (r == P - 1) != (c->bx.hi[1] == c->dom.hi[1])) return bad("box_lo/box_hi inconsistent with rank_xy");
-            if (c->bx.hi[1] - c->bx.lo[1] + 1 < 4) return bad("a slab must be at least 4 rows thick (ghost width 3 + shared face)");
+            if ((r == 0) != (c->bx.lo[d] == c->dom.lo[d]) || (r == P - 1) != (c->bx.hi[d] == c->dom.hi[d])) return bad("box_lo/box_hi inconsistent with rank_xy");
+            if (c->bx.hi[d] - c->bx.lo[d] + 1 < 4) return bad("a box must be at least 4 cells wide in a decomposed direction (ghost width 3 + shared face)");
         }
     }
     for (int d = 0; d < 2; d++) if (prm->periodic[d] && (c->dom.hi[d] - c->dom.lo[d] + 1) < 4) return bad("periodic direction shorter than the ghost width");
-    c->bcq = bc_queue_new();
+    c->bcq = bc_queue_new(); c->haloq = halo_queue_new();
     c->nfast = set_weights(prm->ndtfast, c->w1, c->w2);
     init_bcs(c);
     c->unfused = getenv("RH_UNFUSED") && atoi(getenv("RH_UNFUSED")) != 0;

@@ -46,85 +46,210 @@ __global__ void k_fill_periodic(A4 a, B3 v, int icomp, int ncomp, int perx, int 
     }
 }
 
-// ---- j-slab decomposition: rows exchanged with the lower / upper neighbour -------------------------------------
-// Geometry only (host, no device).  With an index type that is nodal in j the top valid row (hi_j + 1) is shared with the
-// upper neighbour and is not exchanged: FillBoundary fills ghost points only.
-static int plan_j(const rh_params &P, const int alo[3], const int ahi[3], const int ng[3], rh_halo_plan *o)
+// ---- i-j decomposition: ghost blocks exchanged with the neighbours of the process grid -------------------------------
+// FillBoundary across ranks runs in two phases, X then Y.  Phase X swaps ghost COLUMNS with the left /
+// right neighbour over the valid rows only; phase Y swaps ghost ROWS with the lower / upper neighbour over the full width,
+// ghost columns included -- so a corner block reaches its diagonal owner in two hops and no diagonal message exists.  A
+// direction owned by a single rank wraps locally (k_fill_periodic / k_wrap_rows).  Geometry only (host, no device).  With an
+// index type that is nodal in the exchanged direction the last valid face (hi + 1) is shared with the upper neighbour and is
+// not exchanged: FillBoundary fills ghost points only.
+static int plan_dir(const rh_params &P, int d, const int alo[3], const int ahi[3], const int ng[3], rh_halo_plan *o)
 {
-    const int np = P.nranks[1] < 1 ? 1 : P.nranks[1], r = P.rank_xy[1];
-    const int vlo = alo[1] + ng[1], vhi = ahi[1] - ng[1];                       // valid rows of this array
-    const int iy = (vhi - vlo) - (P.box_hi[1] - P.box_lo[1]);                   // 1 if nodal in j
-    if (iy != 0 && iy != 1) return rh_fail("halo plan: array rows [%d,%d] with ghost width %d do not match the rank's box rows [%d,%d]", alo[1], ahi[1], ng[1], P.box_lo[1], P.box_hi[1]);
-    if (vlo != P.box_lo[1]) return rh_fail("halo plan: array does not start at the rank's first row");
-    o->nrows = ng[1];
-    o->peer_lo = (r > 0) ? r - 1 : (P.periodic[1] ? np - 1 : -1);
-    o->peer_hi = (r < np - 1) ? r + 1 : (P.periodic[1] ? 0 : -1);
-    if (np == 1) { o->peer_lo = o->peer_hi = -1; }                              // a single rank wraps locally
-    if (P.periodic[0]) { o->i_lo = alo[0]; o->i_hi = ahi[0]; } else { o->i_lo = alo[0] + ng[0]; o->i_hi = ahi[0] - ng[0]; }
-    o->recv_lo_j = vlo - ng[1];            o->recv_hi_j = vhi + 1;
-    o->send_hi_j = P.box_hi[1] + 1 - ng[1];                                     // the upper neighbour's lower ghost rows
-    o->send_lo_j = P.box_lo[1] + iy;                                            // the lower neighbour's upper ghost rows
-    if (ng[1] > P.box_hi[1] - P.box_lo[1] + 1 - iy) return rh_fail("halo plan: slab thinner than the ghost width");
+    const int o_ = 1 - d;                                                       // the other horizontal direction
+    const int np = P.nranks[d] < 1 ? 1 : P.nranks[d], r = P.rank_xy[d];
+    const int npo = P.nranks[o_] < 1 ? 1 : P.nranks[o_], ro = P.rank_xy[o_];
+    const int vlo = alo[d] + ng[d], vhi = ahi[d] - ng[d];                       // valid range of this array along d
+    const int id = (vhi - vlo) - (P.box_hi[d] - P.box_lo[d]);                   // 1 if nodal along d
+    if (id != 0 && id != 1) return rh_fail("halo plan: array range [%d,%d] with ghost width %d does not match the rank's box range [%d,%d] (direction %d)", alo[d], ahi[d], ng[d], P.box_lo[d], P.box_hi[d], d);
+    if (vlo != P.box_lo[d]) return rh_fail("halo plan: array does not start at the rank's first %s", d ? "row" : "column");
+    o->nrows = ng[d];
+    int c_lo = (r > 0) ? r - 1 : (P.periodic[d] ? np - 1 : -1);
+    int c_hi = (r < np - 1) ? r + 1 : (P.periodic[d] ? 0 : -1);
+    if (np == 1) c_lo = c_hi = -1;                                              // a single rank wraps locally
+    auto rank_of = [&](int cd) { return cd < 0 ? -1 : (d == 1 ? cd * npo + ro : ro * np + cd); };   // rank = ry * npx + rx
+    o->peer_lo = rank_of(c_lo); o->peer_hi = rank_of(c_hi);
+    const int volo = alo[o_] + ng[o_], vohi = ahi[o_] - ng[o_];
+    if (d == 0) { o->i_lo = volo; o->i_hi = vohi; }                             // phase X: valid rows only
+    else {                                                                      // phase Y: ghost columns travel where FillBoundary fills them
+        const bool left = P.periodic[0] || P.rank_xy[0] > 0, right = P.periodic[0] || P.rank_xy[0] < (P.nranks[0] < 1 ? 1 : P.nranks[0]) - 1;
+        o->i_lo = left ? alo[0] : volo; o->i_hi = right ? ahi[0] : vohi;
+    }
+    o->recv_lo_j = vlo - ng[d];            o->recv_hi_j = vhi + 1;
+    o->send_hi_j = P.box_hi[d] + 1 - ng[d];                                     // the upper neighbour's lower ghost block
+    o->send_lo_j = P.box_lo[d] + id;                                            // the lower neighbour's upper ghost block
+    if ((o->peer_lo >= 0 || o->peer_hi >= 0) && ng[d] > P.box_hi[d] - P.box_lo[d] + 1 - id) return rh_fail("halo plan: box thinner than the ghost width (direction %d)", d);
     return 0;
 }
 extern "C" int rh_halo_plan_j(const rh_params *prm, const int arr_lo[3], const int arr_hi[3], const int ng[3], rh_halo_plan *out)
 {
     if (!prm || !out) return rh_fail("rh_halo_plan_j: null argument");
-    return plan_j(*prm, arr_lo, arr_hi, ng, out);
+    return plan_dir(*prm, 1, arr_lo, arr_hi, ng, out);
+}
+extern "C" int rh_halo_plan_i(const rh_params *prm, const int arr_lo[3], const int arr_hi[3], const int ng[3], rh_halo_plan *out)
+{
+    if (!prm || !out) return rh_fail("rh_halo_plan_i: null argument");
+    return plan_dir(*prm, 0, arr_lo, arr_hi, ng, out);
 }
 
-// pack (dir 0) / unpack (dir 1) nrows rows [j0, j0+nrows) x [i0, i1] x all k x ncomp comps; buf is [n][k][row][i]
-__global__ void k_rows(A4 a, double *__restrict__ buf, int dir, int icomp, int ncomp, int i0, int i1, int j0, int nrows)
+// One block of one array travelling through a message slot: [i0, i0+w) x [j0, j0+h) x all k x ncomp comps, packed i fastest.
+struct XDesc { double *p; double *buf; unsigned sy, sz, sn; int i0, j0, w, h, nk, ncomp; };
+#define X_BATCH 16
+struct XBatch { int n, unpack; XDesc q[X_BATCH]; };
+__global__ void k_xblocks(XBatch b)
 {
-    const long w = i1 - i0 + 1; const int nk = a.hi2 - a.lo2 + 1;
-    const long total = w * nrows * nk * ncomp;
+    const XDesc &q = b.q[blockIdx.y];
+    const long w = q.w, h = q.h, total = w * h * q.nk * q.ncomp;
     for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
-        const int i = i0 + (int)(g % w); long r = g / w;
-        const int j = j0 + (int)(r % nrows); r /= nrows;
-        const int k = a.lo2 + (int)(r % nk); const int n = icomp + (int)(r / nk);
-        if (dir == 0) buf[g] = a(i, j, k, n); else a(i, j, k, n) = buf[g];
+        const unsigned i = (unsigned)(g % w); long r = g / w;
+        const unsigned j = (unsigned)(r % h); r /= h;
+        const unsigned k = (unsigned)(r % q.nk), n = (unsigned)(r / q.nk);
+        double *e = q.p + ((unsigned)q.i0 + i) + ((unsigned)q.j0 + j) * q.sy + k * q.sz + n * q.sn;
+        if (b.unpack) *e = q.buf[g]; else q.buf[g] = *e;
+    }
+}
+// local periodic wrap in j of a rank that owns the whole j extent but not the whole i extent: ghost rows over [i0, i0+w)
+__global__ void k_wrap_rows(XDesc q, int nrows, int vlo_off, int vhi_off, int leny)
+{
+    const long w = q.w, total = w * 2 * nrows * q.nk * q.ncomp;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        const unsigned i = (unsigned)(g % w); long r = g / w;
+        const int row = (int)(r % (2 * nrows)); r /= (2 * nrows);
+        const unsigned k = (unsigned)(r % q.nk), n = (unsigned)(r / q.nk);
+        // rows below the valid range copy from leny rows up, rows above it from leny rows down (offsets relative to the array's first row)
+        const int jd = row < nrows ? vlo_off - nrows + row : vhi_off + 1 + (row - nrows);
+        const int js = row < nrows ? jd + leny : jd - leny;
+        double *base = q.p + ((unsigned)q.i0 + i) + k * q.sz + n * q.sn;
+        base[(unsigned)jd * q.sy] = base[(unsigned)js * q.sy];
     }
 }
 
-static int bc_flush_if_pending(rh_ctx *c, const double *p, long n);
-int halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp)
+struct HaloItem { MFV m; int icomp, ncomp; };
+static std::vector<HaloItem> &halo_queue(rh_ctx *c) { return *(std::vector<HaloItem> *)c->haloq; }
+void *halo_queue_new() { return new std::vector<HaloItem>(); }
+void halo_queue_delete(void *q) { delete (std::vector<HaloItem> *)q; }
+
+static int xbuf_reserve(rh_ctx *c, long n)
 {
-    const int np = c->prm.nranks[1] < 1 ? 1 : c->prm.nranks[1];
-    const int perx = c->prm.periodic[0], pery = (np == 1) ? c->prm.periodic[1] : 0;     // decomposed: j handled by the exchange
-    if (icomp < 0 || icomp + ncomp > m.a.ncomp) return rh_fail("halo_fill_boundary: component range");
-    RH_TRY(bc_flush_if_pending(c, m.a.p, a4_size(m.a)));
-    A4 a = mkA(m.a); B3 v = mkB(m.valid);
-    const long NX = a.hi0 - a.lo0 + 1, NY = a.hi1 - a.lo1 + 1, vx = v.hi0 - v.lo0 + 1, vy = v.hi1 - v.lo1 + 1;
-    if (vx <= 0 || vy <= 0 || !bx_contains(bx_of(m.a), m.valid)) return rh_fail("halo_fill_boundary: valid box not inside array");
-    if (perx || pery) {
-        const long total = ((NY - vy) * NX + vy * (NX - vx)) * (a.hi2 - a.lo2 + 1) * ncomp;
-        if (total > 0) {
-            long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
-            k_fill_periodic<<<(int)nb, 256, 0, c->stream>>>(a, v, icomp, ncomp, perx, pery,
-                                                             c->dom.hi[0] - c->dom.lo[0] + 1, c->dom.hi[1] - c->dom.lo[1] + 1);
+    if (n <= c->xcap) return 0;                                                 // grow the message slots (first calls only)
+    RH_HIP(hipStreamSynchronize(c->stream));
+    if (c->d_xbuf) RH_HIP(hipFree(c->d_xbuf));
+    c->xcap = (n + 4095) / 4096 * 4096; c->d_xbuf = nullptr;
+    RH_HIP(hipMalloc((void **)&c->d_xbuf, sizeof(double) * 4 * c->xcap));
+    return 0;
+}
+static int xbatch_go(rh_ctx *c, XBatch &b, long big)
+{
+    if (!b.n) return 0;
+    long nb = (big + 255) / 256; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
+    k_xblocks<<<dim3((unsigned)nb, (unsigned)b.n, 1), 256, 0, c->stream>>>(b);
+    b.n = 0;
+    RH_LAUNCH_CHECK(); return 0;
+}
+
+// one phase (d = 0: X, d = 1: Y) of the neighbour exchange for a list of arrays: one pack launch, one message per neighbour, one unpack launch
+static int exchange_phase(rh_ctx *c, const std::vector<HaloItem> &items, int d)
+{
+    std::vector<rh_halo_plan> pl(items.size());
+    long n = 0; int peer_lo = -1, peer_hi = -1;
+    for (size_t q = 0; q < items.size(); q++) {
+        const HaloItem &it = items[q];
+        RH_TRY(plan_dir(c->prm, d, it.m.a.lo, it.m.a.hi, it.m.ng, &pl[q]));
+        if (pl[q].nrows <= 0) continue;
+        const long w = pl[q].i_hi - pl[q].i_lo + 1;
+        n += w * pl[q].nrows * (it.m.a.hi[2] - it.m.a.lo[2] + 1) * it.ncomp;
+        peer_lo = pl[q].peer_lo; peer_hi = pl[q].peer_hi;                       // the same for every array of this rank
+    }
+    if (n <= 0 || (peer_lo < 0 && peer_hi < 0)) return 0;
+    if (!c->xfn && !c->comm) return rh_fail("halo_fill_boundary: decomposed run without a communicator (call rh_comm_init or rh_comm_set_exchange)");
+    RH_TRY(xbuf_reserve(c, n));
+    double *slot[4] = {c->d_xbuf, c->d_xbuf + c->xcap, c->d_xbuf + 2 * c->xcap, c->d_xbuf + 3 * c->xcap};   // send_lo, send_hi, recv_lo, recv_hi
+    for (int unpack = 0; unpack < 2; unpack++) {
+        XBatch b; b.n = 0; b.unpack = unpack; long big = 0, off = 0;
+        for (size_t q = 0; q < items.size(); q++) {
+            const HaloItem &it = items[q]; const rh_halo_plan &p = pl[q];
+            if (p.nrows <= 0) continue;
+            const A4 a = mkA(it.m.a, it.icomp);
+            const int nk = a.hi2 - a.lo2 + 1;
+            const long wo = p.i_hi - p.i_lo + 1, cnt = wo * p.nrows * nk * it.ncomp;
+            for (int side = 0; side < 2; side++) {
+                if ((side == 0 ? peer_lo : peer_hi) < 0) continue;
+                const int first = unpack ? (side == 0 ? p.recv_lo_j : p.recv_hi_j) : (side == 0 ? p.send_lo_j : p.send_hi_j);
+                XDesc x; x.p = a.p; x.buf = slot[2 * unpack + side] + off; x.sy = a.sy; x.sz = a.sz; x.sn = a.sn; x.nk = nk; x.ncomp = it.ncomp;
+                if (d == 0) { x.i0 = first - a.lo0; x.w = p.nrows; x.j0 = p.i_lo - a.lo1; x.h = (int)wo; }
+                else        { x.j0 = first - a.lo1; x.h = p.nrows; x.i0 = p.i_lo - a.lo0; x.w = (int)wo; }
+                if (x.i0 < 0 || x.j0 < 0 || x.i0 + x.w > (int)a.sy || x.j0 + x.h > a.hi1 - a.lo1 + 1) return rh_fail("halo exchange: block outside the array");
+                b.q[b.n++] = x; big = std::max(big, cnt);
+                if (b.n == X_BATCH) RH_TRY(xbatch_go(c, b, big));
+            }
+            off += cnt;
+        }
+        RH_TRY(xbatch_go(c, b, big));
+        if (!unpack) RH_TRY(comm_exchange(c, peer_lo >= 0 ? n : 0, peer_lo, peer_hi >= 0 ? n : 0, peer_hi));
+    }
+    return 0;
+}
+
+static bool bc_pending_on(rh_ctx *c, const double *p, long n);
+// FillBoundary of a list of arrays (each one distinct): local periodic wraps, then the two exchange phases, batched over the list
+static int halo_fill_list(rh_ctx *c, const std::vector<HaloItem> &items)
+{
+    const int npx = c->prm.nranks[0] < 1 ? 1 : c->prm.nranks[0], npy = c->prm.nranks[1] < 1 ? 1 : c->prm.nranks[1];
+    const int lenx = c->dom.hi[0] - c->dom.lo[0] + 1, leny = c->dom.hi[1] - c->dom.lo[1] + 1;
+    // a direction wraps locally when one rank owns all of it; the j wrap of an i-decomposed run waits for phase X (it carries ghost columns)
+    const int perx = (npx == 1) ? c->prm.periodic[0] : 0, pery = (npy == 1 && npx == 1) ? c->prm.periodic[1] : 0;
+    for (const HaloItem &it : items) {
+        const A4 a = mkA(it.m.a); const B3 v = mkB(it.m.valid);
+        const long NX = a.hi0 - a.lo0 + 1, NY = a.hi1 - a.lo1 + 1, vx = v.hi0 - v.lo0 + 1, vy = v.hi1 - v.lo1 + 1;
+        if (vx <= 0 || vy <= 0 || !bx_contains(bx_of(it.m.a), it.m.valid)) return rh_fail("halo_fill_boundary: valid box not inside array");
+        if (perx || pery) {
+            const long total = ((NY - vy) * NX + vy * (NX - vx)) * (a.hi2 - a.lo2 + 1) * it.ncomp;
+            if (total > 0) {
+                long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
+                k_fill_periodic<<<(int)nb, 256, 0, c->stream>>>(a, v, it.icomp, it.ncomp, perx, pery, lenx, leny);
+                RH_LAUNCH_CHECK();
+            }
+        }
+    }
+    if (npx == 1 && npy == 1) return 0;
+    if (npx > 1) RH_TRY(exchange_phase(c, items, 0));
+    if (npy > 1) RH_TRY(exchange_phase(c, items, 1));
+    else if (npx > 1 && c->prm.periodic[1]) {
+        for (const HaloItem &it : items) {
+            rh_halo_plan p; RH_TRY(plan_dir(c->prm, 1, it.m.a.lo, it.m.a.hi, it.m.ng, &p));
+            if (p.nrows <= 0) continue;
+            const A4 a = mkA(it.m.a, it.icomp);
+            XDesc x; x.p = a.p; x.buf = nullptr; x.sy = a.sy; x.sz = a.sz; x.sn = a.sn; x.nk = a.hi2 - a.lo2 + 1; x.ncomp = it.ncomp;
+            x.i0 = p.i_lo - a.lo0; x.w = p.i_hi - p.i_lo + 1; x.j0 = 0; x.h = 0;
+            const long total = (long)x.w * 2 * p.nrows * x.nk * x.ncomp;
+            long nb = (total + 255) / 256; if (nb > 1024) nb = 1024;
+            k_wrap_rows<<<(int)nb, 256, 0, c->stream>>>(x, p.nrows, it.m.valid.lo[1] - a.lo1, it.m.valid.hi[1] - a.lo1, leny);
             RH_LAUNCH_CHECK();
         }
     }
-    if (np == 1) return 0;
-    // ---- neighbour exchange in j (the x wrap above has already filled the x ghost columns of the rows that travel)
-    rh_halo_plan pl;
-    RH_TRY(plan_j(c->prm, m.a.lo, m.a.hi, m.ng, &pl));
-    if (pl.nrows <= 0 || (pl.peer_lo < 0 && pl.peer_hi < 0)) return 0;
-    if (!c->xfn && !c->comm) return rh_fail("halo_fill_boundary: decomposed run without a communicator (call rh_comm_init or rh_comm_set_exchange)");
-    const long w = pl.i_hi - pl.i_lo + 1, n = w * pl.nrows * (a.hi2 - a.lo2 + 1) * ncomp;
-    if (n > c->xcap) {                                                          // grow the message slots (first calls only)
-        RH_HIP(hipStreamSynchronize(c->stream));
-        if (c->d_xbuf) RH_HIP(hipFree(c->d_xbuf));
-        c->xcap = (n + 4095) / 4096 * 4096; c->d_xbuf = nullptr;
-        RH_HIP(hipMalloc((void **)&c->d_xbuf, sizeof(double) * 4 * c->xcap));
-    }
-    double *s_lo = c->d_xbuf, *s_hi = c->d_xbuf + c->xcap, *r_lo = c->d_xbuf + 2 * c->xcap, *r_hi = c->d_xbuf + 3 * c->xcap;
-    long nb = (n + 255) / 256; if (nb > 2048) nb = 2048;
-    if (pl.peer_lo >= 0) { k_rows<<<(int)nb, 256, 0, c->stream>>>(a, s_lo, 0, icomp, ncomp, pl.i_lo, pl.i_hi, pl.send_lo_j, pl.nrows); RH_LAUNCH_CHECK(); }
-    if (pl.peer_hi >= 0) { k_rows<<<(int)nb, 256, 0, c->stream>>>(a, s_hi, 0, icomp, ncomp, pl.i_lo, pl.i_hi, pl.send_hi_j, pl.nrows); RH_LAUNCH_CHECK(); }
-    RH_TRY(comm_exchange(c, pl.peer_lo >= 0 ? n : 0, pl.peer_lo, pl.peer_hi >= 0 ? n : 0, pl.peer_hi));
-    if (pl.peer_lo >= 0) { k_rows<<<(int)nb, 256, 0, c->stream>>>(a, r_lo, 1, icomp, ncomp, pl.i_lo, pl.i_hi, pl.recv_lo_j, pl.nrows); RH_LAUNCH_CHECK(); }
-    if (pl.peer_hi >= 0) { k_rows<<<(int)nb, 256, 0, c->stream>>>(a, r_hi, 1, icomp, ncomp, pl.i_lo, pl.i_hi, pl.recv_hi_j, pl.nrows); RH_LAUNCH_CHECK(); }
+    return 0;
+}
+
+int halo_flush(rh_ctx *c)
+{
+    std::vector<HaloItem> &Q = halo_queue(c);
+    if (Q.empty()) return 0;
+    std::vector<HaloItem> items; items.swap(Q);
+    return halo_fill_list(c, items);
+}
+
+int halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp)
+{
+    if (icomp < 0 || icomp + ncomp > m.a.ncomp) return rh_fail("halo_fill_boundary: component range");
+    if (a4_size(m.a) >= (1L << 32)) return rh_fail("halo_fill_boundary: array too large for 32-bit indexing");
+    std::vector<HaloItem> &Q = halo_queue(c);
+    // order: a fill never overtakes queued work on the same array (an earlier fill of it, or BC passes that read its ghost cells)
+    bool clash = false;
+    for (const HaloItem &q : Q) if (q.m.a.p == m.a.p) clash = true;
+    if (clash) { RH_TRY(halo_flush(c)); RH_TRY(bc_flush(c)); }
+    else if (bc_pending_on(c, m.a.p, a4_size(m.a))) { RH_TRY(halo_flush(c)); RH_TRY(bc_flush(c)); }
+    HaloItem it; it.m = m; it.icomp = icomp; it.ncomp = ncomp;
+    Q.push_back(it);
+    if (c->bc_defer <= 0) return halo_flush(c);
     return 0;
 }
 
@@ -171,6 +296,7 @@ void bc_queue_delete(void *q) { delete (std::vector<BcPending> *)q; }
 
 int bc_flush(rh_ctx *c)
 {
+    RH_TRY(halo_flush(c));                                // queued ghost exchanges land before the BC passes that read them
     std::vector<BcPending> &Q = *(std::vector<BcPending> *)c->bcq;
     if (Q.empty()) return 0;
     int maxl = 0; for (const BcPending &p : Q) maxl = std::max(maxl, p.level);
@@ -193,11 +319,11 @@ int bc_flush(rh_ctx *c)
 void bc_begin(rh_ctx *c) { c->bc_defer++; }
 int  bc_end(rh_ctx *c) { if (--c->bc_defer <= 0) { c->bc_defer = 0; return bc_flush(c); } return 0; }
 // queued passes on [p, p + n) must land before anything else touches that memory
-static int bc_flush_if_pending(rh_ctx *c, const double *p, long n)
+static bool bc_pending_on(rh_ctx *c, const double *p, long n)
 {
     std::vector<BcPending> &Q = *(std::vector<BcPending> *)c->bcq;
-    for (const BcPending &q : Q) if (q.q.d >= p && q.q.d < p + n) return bc_flush(c);
-    return 0;
+    for (const BcPending &q : Q) if (q.q.d >= p && q.q.d < p + n) return true;
+    return false;
 }
 
 static int bc_pass(rh_ctx *c, const rh_array4 &dest, int comp, rh_box r, int mode, int si, int sj, double val, const rh_array4 *msk)

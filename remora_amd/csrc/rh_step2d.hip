@@ -386,8 +386,12 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
     k2d_flux<<<grid2(tbxp3), rh_block(), 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkA(zeta_rhs), mkA(s->h), mkA(ub_rhs), mkA(vb_rhs),
         mkA(s->pm), mkA(s->pn), mkA(c->DUon), mkA(c->DVom));
     RH_LAUNCH_CHECK();
-    RH_TRY(halo_fill_boundary(c, mfv(c, c->DUon, 1, 0, 0), 0, 1));
-    RH_TRY(halo_fill_boundary(c, mfv(c, c->DVom, 0, 1, 0), 0, 1));
+    {
+        BcScope xs(c);                                                         // both arrays share one message per neighbour
+        RH_TRY(halo_fill_boundary(c, mfv(c, c->DUon, 1, 0, 0), 0, 1));
+        RH_TRY(halo_fill_boundary(c, mfv(c, c->DVom, 0, 1, 0), 0, 1));
+        RH_TRY(xs.end());
+    }
 
     // ---- averages + free surface
     ZetaPar zp; memset(&zp, 0, sizeof zp);

@@ -1,5 +1,5 @@
-"""Worker of tests/test_gpu_decomp.py: one rank of a j-slab decomposed run (all ranks share cuda:0; messages travel through
-the transport hook + gloo).  Rank 0 also runs the same case as a single box and checks that every rank's valid region is
+"""Worker of tests/test_gpu_decomp.py: one rank of an i-j decomposed run (all ranks share cuda:0; messages travel through
+the transport hook + gloo; argv[3] = "PXxPY" process grid, default 1 x world = j-slabs).  Rank 0 also runs the same case as a single box and checks that every rank's valid region is
 BIT-IDENTICAL to it (multi-GPU must reproduce the 1-GPU result)."""
 import os
 import sys
@@ -38,8 +38,12 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     cfg = cases.get(case)
     nx, ny, nz = cfg["ncell"]
-    jlo, jhi = slab_rows(ny, world, rank)
-    rem = REMORA(cfg, device="cuda:0", box=((0, jlo, 0), (nx - 1, jhi, nz - 1)), nranks=(1, world), rank_xy=(0, rank))
+    px, py = (int(x) for x in sys.argv[3].split("x")) if len(sys.argv) > 3 else (1, world)
+    assert px * py == world
+    rx, ry = rank % px, rank // px
+    jlo, jhi = slab_rows(ny, py, ry)
+    ilo, ihi = slab_rows(nx, px, rx)
+    rem = REMORA(cfg, device="cuda:0", box=((ilo, jlo, 0), (ihi, jhi, nz - 1)), nranks=(px, py), rank_xy=(rx, ry))
     rem.comm_set_host_transport(dist)
     rem.InitData()
     rem.Evolve(nsteps)
@@ -49,7 +53,7 @@ def main():
         a, lo, hi = rem.get(f)
         mine[f] = (a, lo, hi)
     gathered = [None] * world
-    dist.gather_object((jlo, jhi, mine), gathered if rank == 0 else None, dst=0)
+    dist.gather_object((ilo, ihi, jlo, jhi, mine), gathered if rank == 0 else None, dst=0)
     ok = True
     if rank == 0:
         ref = REMORA(cfg, device="cuda:0")
@@ -60,10 +64,11 @@ def main():
             gng1 = -glo[1]
             nod_j = (ghi[1] - glo[1] + 1) - 2 * gng1 - ny
             gng0 = -glo[0]
-            for (sjlo, sjhi, fields) in gathered:
+            nod_i = (ghi[0] - glo[0] + 1) - 2 * gng0 - nx
+            for (silo, sihi, sjlo, sjhi, fields) in gathered:
                 a, lo, hi = fields[f]
-                j0, j1 = sjlo, sjhi + nod_j                      # valid rows of this slab's array
-                i0, i1 = glo[0] + gng0, ghi[0] - gng0            # valid i
+                j0, j1 = sjlo, sjhi + nod_j                      # valid rows of this box's array
+                i0, i1 = silo, sihi + nod_i                      # valid columns
                 x = a[:, :, j0 - lo[1]:j1 - lo[1] + 1, i0 - lo[0]:i1 - lo[0] + 1]
                 y = g[:, :, j0 - glo[1]:j1 - glo[1] + 1, i0 - glo[0]:i1 - glo[0] + 1]
                 if f in ("rubar", "rvbar"):
@@ -72,7 +77,10 @@ def main():
                     # fills (in the reference's own multi-box runs as well).  Compare it away from non-periodic wall faces.
                     x = x.copy(); y = y.copy()
                     if f == "rubar" and not cfg["periodic"][0]:
-                        x[..., 0] = y[..., 0] = 0.0; x[..., -1] = y[..., -1] = 0.0
+                        if i0 == 0:
+                            x[..., 0] = y[..., 0] = 0.0
+                        if i1 == nx:
+                            x[..., -1] = y[..., -1] = 0.0
                     if f == "rvbar" and not cfg["periodic"][1]:
                         if j0 == 0:
                             x[:, :, 0, :] = y[:, :, 0, :] = 0.0
@@ -81,7 +89,7 @@ def main():
                 if not np.array_equal(x, y):
                     ok = False
                     w = np.argwhere(x != y)
-                    print(f"MISMATCH {case} field {f} slab rows {sjlo}-{sjhi}: max |diff| = {np.nanmax(np.abs(x - y)):.3e} at {len(w)} points; "
+                    print(f"MISMATCH {case} field {f} box i {silo}-{sihi} j {sjlo}-{sjhi}: max |diff| = {np.nanmax(np.abs(x - y)):.3e} at {len(w)} points; "
                           f"comps {sorted(set(w[:, 0]))} i {sorted(set(w[:, 3] + i0))[:8]} j {sorted(set(w[:, 2] + j0))[:8]}", flush=True)
         print(("DECOMP_OK" if ok else "DECOMP_FAIL"), case, "world", world, "steps", nsteps, flush=True)
         ref.close()

@@ -1,5 +1,5 @@
-"""j-slab decomposition on the GPU: 2 and 3 ranks (processes sharing the box's single GPU, messages through the transport
-hook over gloo) must reproduce the single-box run bit for bit in every valid region."""
+"""i-j decomposition on the GPU: 2 to 4 ranks (processes sharing the box's single GPU, messages through the transport hook
+over gloo) on j-slab, i-slab and 2 x 2 process grids must reproduce the single-box run bit for bit in every valid region."""
 import os
 import subprocess
 import sys
@@ -10,11 +10,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("case,world,port", [("Seamount", 2, 29611), ("Upwelling", 3, 29612), ("DoubleGyre", 3, 29613), ("Advection", 2, 29614)])
-def test_decomposed_equals_single_box(case, world, port):
+@pytest.mark.parametrize("case,world,port,grid", [("Seamount", 2, 29611, "1x2"), ("Upwelling", 3, 29612, "1x3"), ("DoubleGyre", 3, 29613, "1x3"),
+                                                  ("Advection", 2, 29614, "1x2"), ("Seamount", 4, 29615, "2x2"), ("Upwelling", 2, 29616, "2x1"),
+                                                  ("DoubleGyre", 4, 29617, "2x2"), ("Advection", 3, 29618, "3x1")])
+def test_decomposed_equals_single_box(case, world, port, grid):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "tests", "decomp_worker.py"), case, "3"]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "decomp_worker.py"), case, "3", grid]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     out = r.stdout + r.stderr
     assert r.returncode == 0 and "DECOMP_OK" in out, out[-4000:]

@@ -106,3 +106,106 @@ def test_plan_exchange_equals_fill_boundary(world, perx, pery, nod_i, nod_j):
     for p in procs:
         p.join(60)
     assert all(b == 0 for _, b in res), res
+
+
+# ---- two-phase exchange on an i-j process grid (phase X: rh_halo_plan_i, phase Y: rh_halo_plan_j) ---------------------------
+def _worker_ij(rank, px, py, port, nx, ny, nz, perx, pery, ng, nod_i, nod_j, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    world = px * py
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from remora_amd import lib as L
+    lib = L.load()
+    rx, ry = rank % px, rank // px
+    ilo, ihi = _slab(nx, px, rx)
+    jlo, jhi = _slab(ny, py, ry)
+    p = L.Params()
+    for d, n in enumerate((nx, ny, nz)):
+        p.domain_lo[d] = 0; p.domain_hi[d] = n - 1
+    p.box_lo[0] = ilo; p.box_hi[0] = ihi; p.box_lo[1] = jlo; p.box_hi[1] = jhi; p.box_lo[2] = 0; p.box_hi[2] = nz - 1
+    p.periodic[0] = perx; p.periodic[1] = pery; p.nranks[0] = px; p.nranks[1] = py; p.rank_xy[0] = rx; p.rank_xy[1] = ry
+    alo = (C.c_int * 3)(ilo - ng, jlo - ng, 0); ahi = (C.c_int * 3)(ihi + nod_i + ng, jhi + nod_j + ng, nz - 1)
+    ngv = (C.c_int * 3)(ng, ng, 0)
+    NI, NJ = ahi[0] - alo[0] + 1, ahi[1] - alo[1] + 1
+    a = np.full((nz, NJ, NI), np.nan)
+    for k in range(nz):
+        for j in range(jlo, jhi + nod_j + 1):
+            for i in range(ilo, ihi + nod_i + 1):
+                a[k, j - alo[1], i - alo[0]] = _gval(i, j, k, nx, ny, 0, 0, nod_i, nod_j)
+
+    def local_wrap(d, n, nod, lo_idx):
+        # a direction owned by one rank wraps locally (only reached with px == 1 or py == 1)
+        valid_hi = n - 1 + nod
+        for g in list(range(lo_idx, 0)) + list(range(valid_hi + 1, valid_hi + ng + 1)):
+            src = g % n
+            if d == 0:
+                a[:, jlo - alo[1]:jhi + nod_j - alo[1] + 1, g - alo[0]] = a[:, jlo - alo[1]:jhi + nod_j - alo[1] + 1, src - alo[0]]
+            else:
+                a[:, g - alo[1], :] = a[:, src - alo[1], :]
+
+    def phase(d):
+        pl = L.HaloPlan()
+        fn = lib.rh_halo_plan_i if d == 0 else lib.rh_halo_plan_j
+        assert fn(C.byref(p), alo, ahi, ngv, C.byref(pl)) == 0, lib.rh_last_error()
+        o0, o1 = pl.i_lo - alo[1 - d], pl.i_hi - alo[1 - d] + 1
+
+        def blk(first):
+            f = first - alo[d]
+            return a[:, o0:o1, f:f + pl.nrows] if d == 0 else a[:, f:f + pl.nrows, o0:o1]
+        reqs, recvs = [], []
+        for peer, first, tag in ((pl.peer_lo, pl.send_lo_j, 0), (pl.peer_hi, pl.send_hi_j, 1)):
+            if peer >= 0:
+                reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(blk(first))), dst=peer, tag=tag))
+        for peer, first, tag in ((pl.peer_hi, pl.recv_hi_j, 0), (pl.peer_lo, pl.recv_lo_j, 1)):
+            if peer >= 0:
+                t = torch.empty(blk(first).shape, dtype=torch.float64)
+                reqs.append(dist.irecv(t, src=peer, tag=tag)); recvs.append((first, t))
+        for r in reqs:
+            r.wait()
+        for first, t in recvs:
+            blk(first)[...] = t.numpy()
+
+    if px == 1 and perx:
+        local_wrap(0, nx, nod_i, alo[0])
+    if px > 1:
+        phase(0)
+    if py > 1:
+        phase(1)
+    elif pery:
+        # rows wrap over the columns FillBoundary fills: restrict to them by restoring NaN elsewhere afterwards
+        keep = a.copy()
+        local_wrap(1, ny, nod_j, alo[1])
+        left = perx or rx > 0; right = perx or rx < px - 1
+        if not left:
+            a[:, :, :ng] = keep[:, :, :ng]
+        if not right:
+            a[:, :, NI - ng:] = keep[:, :, NI - ng:]
+    bad = 0
+    for k in (0, nz - 1):
+        for j in range(alo[1], ahi[1] + 1):
+            for i in range(alo[0], ahi[0] + 1):
+                e = _gval(i, j, k, nx, ny, perx, pery, nod_i, nod_j)
+                # this rank's own valid points keep their own value even where the periodic image differs (shared nodes)
+                g = a[k, j - alo[1], i - alo[0]]
+                if np.isnan(e):
+                    bad += 0 if np.isnan(g) else 1
+                else:
+                    bad += 0 if g == e else 1
+    q.put((rank, bad))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("px,py,perx,pery,nod_i,nod_j", [(2, 2, 1, 1, 0, 0), (2, 2, 0, 0, 1, 0), (2, 2, 1, 0, 0, 1), (2, 1, 1, 1, 1, 0), (3, 1, 0, 1, 0, 0),
+                                                         (2, 2, 0, 1, 0, 0)])
+def test_two_phase_exchange_equals_fill_boundary(px, py, perx, pery, nod_i, nod_j):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + px * 32 + py * 16 + perx * 8 + pery * 4 + nod_i * 2 + nod_j
+    procs = [ctx.Process(target=_worker_ij, args=(r, px, py, port, 13, 17, 2, perx, pery, 3, nod_i, nod_j, q)) for r in range(px * py)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(b == 0 for _, b in res), res
