@@ -304,6 +304,314 @@ k2d_uvbar(B3 xb, B3 yb, B3 un, B3 rb, UVPar P, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, 
     }
 }
 
+// ---- the whole call in one kernel -------------------------------------------------------------------------------
+// k2d_flux + k2d_zeta + k2d_uvbar of one advance_2d call fused: DUon, DVom, Drhs, zwrk, Dnew, gzeta* never reach memory (the
+// three-kernel form moves ~67 doubles per column and call, this one ~35).  Each block first rebuilds what it needs of
+// Drhs / DUon / DVom on its 64 x 8 points plus a halo of 2 (68 x 12 tiles in LDS, same expressions as k2d_flux, so the values are
+// bitwise those of the scratch FABs), steps the free surface on its own points, and then runs the two phases of k2d_uvbar with
+// the tiles in place of the arrays.  The tiles alias the flux slots (they are dead once phase 1 has its values in registers).
+// Points of tbxp1 are owned by exactly one thread (blocks overlap by one row / column): only the owner accumulates the time
+// averages and stores zeta(knew) / rzeta.  The ghost frame outside tbxp1 gets its averages from k2d_frame.
+// The FillBoundary of DUon / DVom (:170-171) is NOT redundant: a ghost face rebuilt from ghost ubar / vbar can differ from its
+// owner's value (the BC routines skip the outermost ghost row, REMORA_BoundaryConditions_xvel.cpp:56-134, so e.g. a wall face there
+// keeps its pre-BC value).  Where that FillBoundary has work to do (a periodic direction, or neighbour ranks) the ghost faces are
+// therefore built and filled the reference's way first -- k2d_flux_frame on the rim + halo_fill_boundary -- and the tiles take their
+// ghost faces from memory (ghost_from_mem); the valid faces are always rebuilt here.
+#define F_PX (RT_BX + 4)
+#define F_PY (U_BY + 4)
+struct FTile { const double *s; int i0, j0; __device__ __forceinline__ double operator()(int i, int j, int) const { return s[(j - j0) * F_PX + (i - i0)]; } };
+enum { Q_ZN = Q_N, QF_N };
+__global__ void __launch_bounds__(RT_BX * U_BY)
+k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, A4 vb_stp, A4 ub_new, A4 vb_new,
+          A4 rubar_rhs, A4 rvbar_rhs, A4 rubar_stp, A4 rvbar_stp, A4 rubar_pts, A4 rvbar_pts,
+          A4 zeta_rhs, A4 zeta_stp, A4 zeta_new, A4 rzeta_stp, A4 rzeta_pts, A4 rzeta_rhs,
+          A4 h, A4 pm, A4 pn, A4 fcor, A4 rhoS, A4 rhoA, A4 mskr, A4 msku, A4 mskv, A4 mskp, A4 visc2_p, A4 visc2_r,
+          A4 rufrc, A4 rvfrc, A4 ru2d, A4 rv2d, A4 Zt_avg1, A4 DU_avg1, A4 DU_avg2, A4 DV_avg1, A4 DV_avg2, A4 DUon_g, A4 DVom_g, int ghost_from_mem)
+{
+    constexpr int NT = RT_BX * U_BY;
+    __shared__ double lds[QF_N * NT];
+    static_assert(3 * F_PX * F_PY <= QF_N * NT, "tiles alias the flux slots");
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
+    const RhTile rh_t_ = rh_tile();
+    const int I0 = un.lo0 - 1 + rh_t_.x * U_SX, J0 = un.lo1 - 1 + rh_t_.y * U_SY;
+    const int i = I0 + tx, j = J0 + ty;
+    double *tD = lds, *tU = lds + F_PX * F_PY, *tV = lds + 2 * F_PX * F_PY;
+    // ---- Drhs on the tile (advance_2d.cpp:149-152)
+    for (int t = tid; t < F_PX * F_PY; t += NT) {
+        const int y = t / F_PX, x = t - y * F_PX, gi = I0 - 2 + x, gj = J0 - 2 + y;
+        tD[t] = inb2(g3, gi, gj) ? zeta_rhs(gi, gj, 0) + h(gi, gj, 0) : 0.0;
+    }
+    __syncthreads();
+    // ---- DUon, DVom on the tile (:153-166)
+    for (int t = tid; t < F_PX * F_PY; t += NT) {
+        const int y = t / F_PX, x = t - y * F_PX, gi = I0 - 2 + x, gj = J0 - 2 + y;
+        double du = 0.0, dv = 0.0;
+        if (x >= 1 && inb2(xg, gi, gj)) {
+            if (ghost_from_mem && !inb2(xb, gi, gj)) du = DUon_g(gi, gj, 0);   // a ghost face: what FillBoundary left there
+            else {
+                const double on_u = 2.0 / (pn(gi, gj, 0) + pn(gi - 1, gj, 0));
+                const double cff1 = 0.5 * on_u * (tD[t] + tD[t - 1]);
+                du = ub_rhs(gi, gj, 0) * cff1;
+            }
+        }
+        if (y >= 1 && inb2(yg, gi, gj)) {
+            if (ghost_from_mem && !inb2(yb, gi, gj)) dv = DVom_g(gi, gj, 0);
+            else {
+                const double om_v = 2.0 / (pm(gi, gj, 0) + pm(gi, gj - 1, 0));
+                const double cff1 = 0.5 * om_v * (tD[t] + tD[t - F_PX]);
+                dv = vb_rhs(gi, gj, 0) * cff1;
+            }
+        }
+        tU[t] = du; tV[t] = dv;
+    }
+    __syncthreads();
+    const FTile Drhs{tD, I0 - 2, J0 - 2}, DUon{tU, I0 - 2, J0 - 2}, DVom{tV, I0 - 2, J0 - 2};
+    const bool in_rb = inb2(rb, i, j);
+    const bool owner = in_rb && (tx >= 1 || rh_t_.x == 0) && (ty >= 1 || rh_t_.y == 0);
+    // ---- time averages (:293-356) and free surface (:379-464) on this thread's rho point
+    double zn0 = 0.0, zw0 = 0.0;
+    if (in_rb) {
+        const double du0 = DUon(i, j, 0), dv0 = DVom(i, j, 0);
+        if (owner) {
+            if (zp.avg_mode == 0) {
+                Zt_avg1(i, j, 0) = 0.0;
+                DU_avg1(i, j, 0) = 0.0; DU_avg2(i, j, 0) = zp.wt_b * du0;
+                DV_avg1(i, j, 0) = 0.0; DV_avg2(i, j, 0) = zp.wt_b * dv0;
+            } else if (zp.avg_mode == 1) {
+                Zt_avg1(i, j, 0) += zp.wt_a * zeta_rhs(i, j, 0);
+                DU_avg1(i, j, 0) += zp.wt_a * du0; DU_avg2(i, j, 0) += zp.wt_b * du0;
+                DV_avg1(i, j, 0) += zp.wt_a * dv0; DV_avg2(i, j, 0) += zp.wt_b * dv0;
+            } else {
+                DU_avg2(i, j, 0) = DU_avg2(i, j, 0) + zp.wt_b * du0;
+                DV_avg2(i, j, 0) = DV_avg2(i, j, 0) + zp.wt_b * dv0;
+            }
+        }
+        const double div = (du0 - DUon(i + 1, j, 0)) + (dv0 - DVom(i, j + 1, 0));
+        const double zs = zeta_stp(i, j, 0);
+        const double mr = zp.nomask ? 1.0 : mskr(i, j, 0);
+        if (zp.zmode == 0) {
+            const double cff1 = zp.dtfast;
+            zn0 = (zs + pm(i, j, 0) * pn(i, j, 0) * cff1 * div) * mr;
+            zw0 = 0.5 * (zs + zn0);
+        } else if (zp.zmode == 1) {
+            const double cff1 = 2.0 * zp.dtfast, cff4 = 4.0 / 25.0, cff5 = 1.0 - 2.0 * cff4;
+            zn0 = (zs + pm(i, j, 0) * pn(i, j, 0) * cff1 * div) * mr;
+            zw0 = cff5 * zeta_rhs(i, j, 0) + cff4 * (zs + zn0);
+        } else {
+            const double cff1 = zp.dtfast * 5.0 / 12.0, cff2 = zp.dtfast * 8.0 / 12.0, cff3 = zp.dtfast * 1.0 / 12.0, cff4 = 2.0 / 5.0, cff5 = 1.0 - cff4;
+            const double cff = cff1 * div;
+            zn0 = zs + pm(i, j, 0) * pn(i, j, 0) * (cff + cff2 * rzeta_stp(i, j, 0) - cff3 * rzeta_pts(i, j, 0));
+            zn0 *= mr;
+            zw0 = cff5 * zn0 + cff4 * zeta_rhs(i, j, 0);
+        }
+        if (owner) {
+            zeta_new(i, j, 0) = zn0;                                           // :450-454
+            if (zp.predictor) rzeta_rhs(i, j, 0) = div;                        // :459-464
+        }
+    }
+    // ---- phase 1 of k2d_uvbar: the shared quantities of this thread's rho and psi point
+    double *q = lds + tid;
+    const double fac = 1000.0 / 1025.0;
+    double h0 = 0, rA0 = 0, pm0 = 0, pn0 = 0, gz0 = 0, gz20 = 0, gSA0 = 0;
+    double UFx = 0, VFe = 0, mUFx = 0, mVFe = 0, corU = 0, corV = 0, UFe = 0, VFx = 0, mUFe = 0, mVFx = 0;
+    if (in_rb) {
+        h0 = h(i, j, 0); rA0 = rhoA(i, j, 0); pm0 = pm(i, j, 0); pn0 = pn(i, j, 0);
+        const double rS0 = rhoS(i, j, 0);
+        gz0 = (fac + rS0) * zw0; gz20 = gz0 * zw0; gSA0 = zw0 * (rS0 - rA0);
+        UFx = s2_UFx(ub_rhs, DUon, i, j, P);
+        VFe = s2_VFe(vb_rhs, DVom, i, j, P);
+        const MixR r = mix_r_metrics(pm, pn, visc2_r, i, j);
+        const double cffr = mix_r_cff(r, Drhs, ub_rhs, vb_rhs, i, j, 0);
+        mUFx = r.on_r * r.on_r * r.visc * cffr;
+        mVFe = r.om_r * r.om_r * r.visc * cffr;
+        if (P.use_cor) {
+            const double fm = fcor(i, j, 0) * (1.0 / (pm0 * pn0));
+            const double d = Drhs(i, j, 0);
+            corU = 0.5 * d * fm * (vb_rhs(i, j, 0) + vb_rhs(i, j + 1, 0));
+            corV = 0.5 * d * fm * (ub_rhs(i, j, 0) + ub_rhs(i + 1, j, 0));
+        }
+    }
+    if (inb2(un, i, j)) {
+        UFe = s2_UFe(ub_rhs, DVom, i, j, P);
+        VFx = s2_VFx(vb_rhs, DUon, i, j, P);
+        const MixP p = mix_p_metrics(pm, pn, visc2_p, MaskView{mskp, P.nomask}, i, j);
+        const double cffp = mix_p_cff(p, Drhs, ub_rhs, vb_rhs, i, j, 0);
+        mUFe = p.om_p * p.om_p * p.visc * cffp;
+        mVFx = p.on_p * p.on_p * p.visc * cffp;
+    }
+    __syncthreads();                                        // every thread is done with the tiles: the slots may overwrite them
+    q[Q_UFX * NT] = UFx; q[Q_VFE * NT] = VFe; q[Q_MUFX * NT] = mUFx; q[Q_MVFE * NT] = mVFe; q[Q_CORU * NT] = corU; q[Q_CORV * NT] = corV;
+    q[Q_GZ * NT] = gz0; q[Q_GZ2 * NT] = gz20; q[Q_GSA * NT] = gSA0; q[Q_H * NT] = h0; q[Q_ZW * NT] = zw0; q[Q_RA * NT] = rA0;
+    q[Q_PM * NT] = pm0; q[Q_PN * NT] = pn0; q[Q_UFE * NT] = UFe; q[Q_VFX * NT] = VFx; q[Q_MUFE * NT] = mUFe; q[Q_MVFX * NT] = mVFx;
+    q[Q_ZN * NT] = zn0;
+    __syncthreads();
+    // ---- phase 2 of k2d_uvbar
+    const double cffg = 0.5 * P.g, third = 1.0 / 3.0;
+    if (tx >= 1 && ty <= U_BY - 2 && inb2(xb, i, j)) {
+        const double *w = q - 1, *n = q + RT_BX;
+        const double hx = w[Q_H * NT], zwx = w[Q_ZW * NT], rAx = w[Q_RA * NT], pmx = w[Q_PM * NT], pnx = w[Q_PN * NT];
+        const double on_u = 2.0 / (pn0 + pnx);
+        double rhs = cffg * on_u *
+            ((hx + h0) * (w[Q_GZ * NT] - gz0) +
+             (hx - h0) * (w[Q_GSA * NT] + gSA0 + third * (rAx - rA0) * (zwx - zw0)) +
+             (w[Q_GZ2 * NT] - gz20));
+        {
+            const double cff1 = UFx - w[Q_UFX * NT];
+            const double cff2 = n[Q_UFE * NT] - UFe;
+            rhs -= (cff1 + cff2);
+        }
+        if (P.use_cor) rhs += 0.5 * (corU + w[Q_CORU * NT]);
+        {
+            const double cff1 = 0.5 * (pnx + pn0) * (mUFx - w[Q_MUFX * NT]);
+            const double cff2 = 0.5 * (pmx + pm0) * (n[Q_MUFE * NT] - mUFe);
+            rhs += cff1 + cff2;
+        }
+        if (P.couple == 0) rhs += rufrc(i, j, 0);
+        else {
+            double f = rufrc(i, j, 0);
+            if (P.couple == 1) { f -= rhs; rhs += f; ru2d(i, j, 0, 0) = f; }
+            else if (P.couple == 2) {
+                f = f - rhs;
+                const double r0 = ru2d(i, j, 0, 0);
+                rhs = rhs + 1.5 * f - 0.5 * r0;
+                ru2d(i, j, 0, 1) = r0; ru2d(i, j, 0, 0) = f;
+            } else {
+                const double c1 = 23.0 / 12.0, c2 = 16.0 / 12.0, c3 = 5.0 / 12.0;
+                f = f - rhs;
+                const double r0 = ru2d(i, j, 0, 0), r1 = ru2d(i, j, 0, 1);
+                rhs = rhs + c1 * f - c2 * r0 + c3 * r1;
+                ru2d(i, j, 0, 1) = r0; ru2d(i, j, 0, 0) = f;
+            }
+            rufrc(i, j, 0) = f;
+        }
+        const double Dstp0 = zeta_stp(i, j, 0) + h0, Dstp1 = zeta_stp(i - 1, j, 0) + hx;
+        const double cff = (pm0 + pmx) * (pn0 + pnx);
+        const double Dnew_avg = 1.0 / ((zn0 + h0) + (w[Q_ZN * NT] + hx));
+        const double mu = P.nomask ? 1.0 : msku(i, j, 0);
+        if (!P.am3) ub_new(i, j, 0) = (ub_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mu;
+        else ub_new(i, j, 0) = (ub_stp(i, j, 0) * (Dstp0 + Dstp1) +
+                                cff * (P.c1 * rhs + P.c2 * rubar_stp(i, j, 0) - P.c3 * rubar_pts(i, j, 0))) * Dnew_avg * mu;
+        if (P.predictor) rubar_rhs(i, j, 0) = rhs;
+    }
+    if (tx <= RT_BX - 2 && ty >= 1 && inb2(yb, i, j)) {
+        const double *sp = q - RT_BX, *e = q + 1;
+        const double hy = sp[Q_H * NT], zwy = sp[Q_ZW * NT], rAy = sp[Q_RA * NT], pmy = sp[Q_PM * NT], pny = sp[Q_PN * NT];
+        const double om_v = 2.0 / (pm0 + pmy);
+        double rhs = cffg * om_v *
+            ((hy + h0) * (sp[Q_GZ * NT] - gz0) +
+             (hy - h0) * (sp[Q_GSA * NT] + gSA0 + third * (rAy - rA0) * (zwy - zw0)) +
+             (sp[Q_GZ2 * NT] - gz20));
+        {
+            const double cff1 = e[Q_VFX * NT] - VFx;
+            const double cff2 = VFe - sp[Q_VFE * NT];
+            rhs -= (cff1 + cff2);
+        }
+        if (P.use_cor) rhs -= 0.5 * (corV + sp[Q_CORV * NT]);
+        {
+            const double cff1 = 0.5 * (pny + pn0) * (e[Q_MVFX * NT] - mVFx);
+            const double cff2 = 0.5 * (pmy + pm0) * (mVFe - sp[Q_MVFE * NT]);
+            rhs += cff1 - cff2;
+        }
+        if (P.couple == 0) rhs += rvfrc(i, j, 0);
+        else {
+            double f = rvfrc(i, j, 0);
+            if (P.couple == 1) { f -= rhs; rhs += f; rv2d(i, j, 0, 0) = f; }
+            else if (P.couple == 2) {
+                f = f - rhs;
+                const double r0 = rv2d(i, j, 0, 0);
+                rhs = rhs + 1.5 * f - 0.5 * r0;
+                rv2d(i, j, 0, 1) = r0; rv2d(i, j, 0, 0) = f;
+            } else {
+                const double c1 = 23.0 / 12.0, c2 = 16.0 / 12.0, c3 = 5.0 / 12.0;
+                f = f - rhs;
+                const double r0 = rv2d(i, j, 0, 0), r1 = rv2d(i, j, 0, 1);
+                rhs = rhs + c1 * f - c2 * r0 + c3 * r1;
+                rv2d(i, j, 0, 1) = r0; rv2d(i, j, 0, 0) = f;
+            }
+            rvfrc(i, j, 0) = f;
+        }
+        const double Dstp0 = zeta_stp(i, j, 0) + h0, Dstp1 = zeta_stp(i, j - 1, 0) + hy;
+        const double cff = (pm0 + pmy) * (pn0 + pny);
+        const double Dnew_avg = 1.0 / ((zn0 + h0) + (sp[Q_ZN * NT] + hy));
+        const double mv = P.nomask ? 1.0 : mskv(i, j, 0);
+        if (!P.am3) vb_new(i, j, 0) = (vb_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mv;
+        else vb_new(i, j, 0) = (vb_stp(i, j, 0) * (Dstp0 + Dstp1) +
+                                cff * (P.c1 * rhs + P.c2 * rvbar_stp(i, j, 0) - P.c3 * rvbar_pts(i, j, 0))) * Dnew_avg * mv;
+        if (P.predictor) rvbar_rhs(i, j, 0) = rhs;
+    }
+}
+
+// k2d_flux on the rim only: the points of tbxp3 outside `hole` (the valid box shrunk by 3) -- every ghost face and every face a
+// periodic wrap or a neighbour rank takes its ghost values from.  Same enumeration as k2d_frame.
+__global__ void k2d_flux_frame(B3 g3, B3 hole, B3 xg, B3 yg, A4 zeta, A4 h, A4 ubar, A4 vbar, A4 pm, A4 pn, A4 DUon, A4 DVom)
+{
+    const int NX = g3.hi0 - g3.lo0 + 1, NY = g3.hi1 - g3.lo1 + 1, vx = hole.hi0 - hole.lo0 + 1, vy = hole.hi1 - hole.lo1 + 1;
+    const int nglo_x = hole.lo0 - g3.lo0, nglo_y = hole.lo1 - g3.lo1;
+    const int nrow_part = (NY - vy) * NX, total = nrow_part + vy * (NX - vx);
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    int i, j;
+    if (g < nrow_part) { const int row = g / NX; i = g3.lo0 + g % NX; j = row < nglo_y ? g3.lo1 + row : hole.hi1 + 1 + (row - nglo_y); }
+    else { const int r = g - nrow_part, w = NX - vx, row = r / w, cc = r % w; j = hole.lo1 + row; i = cc < nglo_x ? g3.lo0 + cc : hole.hi0 + 1 + (cc - nglo_x); }
+    const double d0 = zeta(i, j, 0) + h(i, j, 0);
+    if (inb2(xg, i, j)) {
+        const double on_u = 2.0 / (pn(i, j, 0) + pn(i - 1, j, 0));
+        const double cff1 = 0.5 * on_u * (d0 + (zeta(i - 1, j, 0) + h(i - 1, j, 0)));
+        DUon(i, j, 0) = ubar(i, j, 0) * cff1;
+    }
+    if (inb2(yg, i, j)) {
+        const double om_v = 2.0 / (pm(i, j, 0) + pm(i, j - 1, 0));
+        const double cff1 = 0.5 * om_v * (d0 + (zeta(i, j - 1, 0) + h(i, j - 1, 0)));
+        DVom(i, j, 0) = vbar(i, j, 0) * cff1;
+    }
+}
+
+// Time averages on the ghost frame: the points of tbxp3 / xgbx2 / ygbx2 outside tbxp1 (k2d_fused owns tbxp1).  One thread per frame
+// point: rows below and above tbxp1 at full width, then the side segments of its rows.  DUon / DVom are formed on the fly.
+__global__ void k2d_frame(B3 g3, B3 xg, B3 yg, B3 t1, ZetaPar zp, A4 zeta_rhs, A4 h, A4 ub_rhs, A4 vb_rhs, A4 pm, A4 pn,
+                          A4 Zt_avg1, A4 DU_avg1, A4 DU_avg2, A4 DV_avg1, A4 DV_avg2, A4 DUon_g, A4 DVom_g, int ghost_from_mem)
+{
+    const int NX = g3.hi0 - g3.lo0 + 1, NY = g3.hi1 - g3.lo1 + 1, vx = t1.hi0 - t1.lo0 + 1, vy = t1.hi1 - t1.lo1 + 1;
+    const int nglo_x = t1.lo0 - g3.lo0, nglo_y = t1.lo1 - g3.lo1;
+    const int nrow_part = (NY - vy) * NX, total = nrow_part + vy * (NX - vx);
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    int i, j;
+    if (g < nrow_part) { const int row = g / NX; i = g3.lo0 + g % NX; j = row < nglo_y ? g3.lo1 + row : t1.hi1 + 1 + (row - nglo_y); }
+    else { const int r = g - nrow_part, w = NX - vx, row = r / w, cc = r % w; j = t1.lo1 + row; i = cc < nglo_x ? g3.lo0 + cc : t1.hi0 + 1 + (cc - nglo_x); }
+    const double d0 = zeta_rhs(i, j, 0) + h(i, j, 0);
+    const bool inx = inb2(xg, i, j), iny = inb2(yg, i, j);
+    double du = 0.0, dv = 0.0;
+    if (inx) {                                             // every frame point is a ghost face of DUon and of DVom
+        if (ghost_from_mem) du = DUon_g(i, j, 0);
+        else {
+            const double on_u = 2.0 / (pn(i, j, 0) + pn(i - 1, j, 0));
+            const double cff1 = 0.5 * on_u * (d0 + (zeta_rhs(i - 1, j, 0) + h(i - 1, j, 0)));
+            du = ub_rhs(i, j, 0) * cff1;
+        }
+    }
+    if (iny) {
+        if (ghost_from_mem) dv = DVom_g(i, j, 0);
+        else {
+            const double om_v = 2.0 / (pm(i, j, 0) + pm(i, j - 1, 0));
+            const double cff1 = 0.5 * om_v * (d0 + (zeta_rhs(i, j - 1, 0) + h(i, j - 1, 0)));
+            dv = vb_rhs(i, j, 0) * cff1;
+        }
+    }
+    if (zp.avg_mode == 0) {
+        Zt_avg1(i, j, 0) = 0.0;
+        if (inx) { DU_avg1(i, j, 0) = 0.0; DU_avg2(i, j, 0) = zp.wt_b * du; }
+        if (iny) { DV_avg1(i, j, 0) = 0.0; DV_avg2(i, j, 0) = zp.wt_b * dv; }
+    } else if (zp.avg_mode == 1) {
+        Zt_avg1(i, j, 0) += zp.wt_a * zeta_rhs(i, j, 0);
+        if (inx) { DU_avg1(i, j, 0) += zp.wt_a * du; DU_avg2(i, j, 0) += zp.wt_b * du; }
+        if (iny) { DV_avg1(i, j, 0) += zp.wt_a * dv; DV_avg2(i, j, 0) += zp.wt_b * dv; }
+    } else {
+        if (inx) DU_avg2(i, j, 0) = DU_avg2(i, j, 0) + zp.wt_b * du;
+        if (iny) DV_avg2(i, j, 0) = DV_avg2(i, j, 0) + zp.wt_b * dv;
+    }
+}
+
 // REMORA::rhs_uv_2d as a leaf of its own (REMORA_rhs_uv_2d.cpp:20-238): rhs_ubar, rhs_vbar -= advection
 __global__ void k_rhs_uv_2d(B3 xb, B3 yb, B3 un, UVPar P, A4 ub, A4 vb, A4 rhs_u, A4 rhs_v, A4 DUon, A4 DVom)
 {
@@ -379,14 +687,24 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
     const rh_array4 zeta_rhs = a4_comp(s->zeta, krhs), zeta_stp = a4_comp(s->zeta, kstp), zeta_new = a4_comp(s->zeta, knew);
     const rh_array4 ub_rhs = a4_comp(s->ubar, krhs), vb_rhs = a4_comp(s->vbar, krhs);
 
+    const bool fused = !c->unfused && !c->nofuse2d && my_iif < nfast;      // the last call only accumulates the averages (:362-363): three-kernel form
     // ---- Drhs, DUon, DVom (:149-166) and their ghost exchange (:170-171)
     RH_NEED(s->zeta, tbxp3); RH_NEED(s->h, tbxp3);
     RH_NEED(s->ubar, xgbx2); RH_NEED(s->vbar, ygbx2); RH_NEED(c->DUon, xgbx2); RH_NEED(c->DVom, ygbx2);
     RH_NEED(s->pn, bx_growlo_i(xgbx2)); RH_NEED(s->pm, bx_growlo_j(ygbx2));
-    k2d_flux<<<grid2(tbxp3), rh_block(), 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkA(zeta_rhs), mkA(s->h), mkA(ub_rhs), mkA(vb_rhs),
-        mkA(s->pm), mkA(s->pn), mkA(c->DUon), mkA(c->DVom));
-    RH_LAUNCH_CHECK();
-    {
+    // FillBoundary of DUon / DVom has work to do only in a periodic direction or next to a neighbour rank
+    const bool fb_work = c->prm.periodic[0] || c->prm.periodic[1] || c->prm.nranks[0] > 1 || c->prm.nranks[1] > 1;
+    const rh_box hole = bx_grow(b2, -3, -3, 0);
+    if (!fused || fb_work) {
+        if (!fused || !bx_ok(hole))
+            k2d_flux<<<grid2(tbxp3), rh_block(), 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkA(zeta_rhs), mkA(s->h), mkA(ub_rhs), mkA(vb_rhs),
+                mkA(s->pm), mkA(s->pn), mkA(c->DUon), mkA(c->DVom));
+        else {
+            const int nfr = (int)(bx_npts(tbxp3) - bx_npts(hole));
+            k2d_flux_frame<<<(nfr + 255) / 256, 256, 0, c->stream>>>(mkB(tbxp3), mkB(hole), mkB(xgbx2), mkB(ygbx2), mkA(zeta_rhs), mkA(s->h), mkA(ub_rhs), mkA(vb_rhs),
+                mkA(s->pm), mkA(s->pn), mkA(c->DUon), mkA(c->DVom));
+        }
+        RH_LAUNCH_CHECK();
         BcScope xs(c);                                                         // both arrays share one message per neighbour
         RH_TRY(halo_fill_boundary(c, mfv(c, c->DUon, 1, 0, 0), 0, 1));
         RH_TRY(halo_fill_boundary(c, mfv(c, c->DVom, 0, 1, 0), 0, 1));
@@ -407,6 +725,7 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
     RH_NEED(s->Zt_avg1, tbxp3); RH_NEED(s->DU_avg1, xgbx2); RH_NEED(s->DU_avg2, xgbx2); RH_NEED(s->DV_avg1, ygbx2); RH_NEED(s->DV_avg2, ygbx2);
     RH_NEED(s->rzeta, tbxp1); RH_NEED(s->pm, tbxp1); RH_NEED(s->pn, tbxp1); RH_NEED(s->mskr, tbxp1); RH_NEED(s->rhoS, tbxp1); RH_NEED(s->rhoA, tbxp1);
     RH_NEED(c->zwrk, tbxp1);
+    if (!fused)
     k2d_zeta<<<grid2(tbxp3), rh_block(), 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkB(tbxp1), zp, mkA(zeta_rhs), mkA(zeta_stp), mkA(zeta_new),
         mkA(a4_comp(s->rzeta, kstp)), mkA(a4_comp(s->rzeta, ptsk)), mkA(a4_comp(s->rzeta, krhs < 2 ? krhs : 0)), mkA(s->h), mkA(s->pm), mkA(s->pn),
         mkA(s->mskr), mkA(s->rhoS), mkA(s->rhoA), mkA(c->DUon), mkA(c->DVom), mkA(s->Zt_avg1), mkA(s->DU_avg1), mkA(s->DU_avg2), mkA(s->DV_avg1), mkA(s->DV_avg2),
@@ -433,6 +752,22 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
         // rubar/rvbar(krhs) only exist for the predictor (krhs < 2); the corrector never writes them
         const int kr = krhs < 2 ? krhs : 0;
         const dim3 grid((un.hi[0] - un.lo[0] + U_SX) / U_SX, (un.hi[1] - un.lo[1] + U_SY) / U_SY, 1);
+        if (fused) {
+            // tiles reach 2 points beyond the block's first / one beyond its last point: inside tbxp3 wherever they are consumed
+            const int nfr = (int)(bx_npts(tbxp3) - bx_npts(tbxp1));
+            k2d_frame<<<(nfr + 255) / 256, 256, 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkB(tbxp1), zp, mkA(zeta_rhs), mkA(s->h), mkA(ub_rhs), mkA(vb_rhs),
+                mkA(s->pm), mkA(s->pn), mkA(s->Zt_avg1), mkA(s->DU_avg1), mkA(s->DU_avg2), mkA(s->DV_avg1), mkA(s->DV_avg2), mkA(c->DUon), mkA(c->DVom), fb_work ? 1 : 0);
+            RH_LAUNCH_CHECK();
+            k2d_fused<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), mkB(tbxp1), mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), P, zp,
+                mkA(ub_rhs), mkA(vb_rhs), mkA(a4_comp(s->ubar, kstp)), mkA(a4_comp(s->vbar, kstp)), mkA(a4_comp(s->ubar, knew)), mkA(a4_comp(s->vbar, knew)),
+                mkA(a4_comp(s->rubar, kr)), mkA(a4_comp(s->rvbar, kr)), mkA(a4_comp(s->rubar, kstp)), mkA(a4_comp(s->rvbar, kstp)),
+                mkA(a4_comp(s->rubar, ptsk)), mkA(a4_comp(s->rvbar, ptsk)),
+                mkA(zeta_rhs), mkA(zeta_stp), mkA(zeta_new), mkA(a4_comp(s->rzeta, kstp)), mkA(a4_comp(s->rzeta, ptsk)), mkA(a4_comp(s->rzeta, kr)),
+                mkA(s->h), mkA(s->pm), mkA(s->pn), mkA(s->fcor), mkA(s->rhoS), mkA(s->rhoA), mkA(s->mskr), mkA(s->msku), mkA(s->mskv), mkA(s->mskp),
+                mkA(s->visc2_p), mkA(s->visc2_r), mkA(s->rufrc), mkA(s->rvfrc), mkA(s->ru2d), mkA(s->rv2d),
+                mkA(s->Zt_avg1), mkA(s->DU_avg1), mkA(s->DU_avg2), mkA(s->DV_avg1), mkA(s->DV_avg2), mkA(c->DUon), mkA(c->DVom), fb_work ? 1 : 0);
+            RH_LAUNCH_CHECK();
+        } else
         k2d_uvbar<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), mkB(tbxp1), P, mkA(ub_rhs), mkA(vb_rhs),
             mkA(a4_comp(s->ubar, kstp)), mkA(a4_comp(s->vbar, kstp)), mkA(a4_comp(s->ubar, knew)), mkA(a4_comp(s->vbar, knew)),
             mkA(a4_comp(s->rubar, kr)), mkA(a4_comp(s->rvbar, kr)), mkA(a4_comp(s->rubar, kstp)), mkA(a4_comp(s->rvbar, kstp)),

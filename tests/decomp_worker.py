@@ -45,9 +45,18 @@ def main():
     ilo, ihi = slab_rows(nx, px, rx)
     rem = REMORA(cfg, device="cuda:0", box=((ilo, jlo, 0), (ihi, jhi, nz - 1)), nranks=(px, py), rank_xy=(rx, ry))
     rem.comm_set_host_transport(dist)
-    rem.InitData()
-    rem.Evolve(nsteps)
-    rem.sync()
+    ncalls = int(sys.argv[4]) if len(sys.argv) > 4 else -1          # debugging aid: stop after ncalls barotropic sub-steps of step 1
+
+    def run(r):
+        r.InitData()
+        if ncalls < 0:
+            r.Evolve(nsteps)
+        else:
+            r.begin_step(); r.setup_step()
+            for q in range(ncalls):
+                r.advance_2d_onestep(q)
+        r.sync()
+    run(rem)
     mine = {}
     for f in FIELDS:
         a, lo, hi = rem.get(f)
@@ -57,8 +66,7 @@ def main():
     ok = True
     if rank == 0:
         ref = REMORA(cfg, device="cuda:0")
-        ref.InitData()
-        ref.Evolve(nsteps)
+        run(ref)
         for f in FIELDS:
             g, glo, ghi = ref.get(f)
             gng1 = -glo[1]
@@ -90,7 +98,7 @@ def main():
                     ok = False
                     w = np.argwhere(x != y)
                     print(f"MISMATCH {case} field {f} box i {silo}-{sihi} j {sjlo}-{sjhi}: max |diff| = {np.nanmax(np.abs(x - y)):.3e} at {len(w)} points; "
-                          f"comps {sorted(set(w[:, 0]))} i {sorted(set(w[:, 3] + i0))[:8]} j {sorted(set(w[:, 2] + j0))[:8]}", flush=True)
+                          f"comps {sorted(set(int(v) for v in w[:, 0]))} i {sorted(set(int(v) for v in w[:, 3] + i0))[:12]} j {sorted(set(int(v) for v in w[:, 2] + j0))[:12]}", flush=True)
         print(("DECOMP_OK" if ok else "DECOMP_FAIL"), case, "world", world, "steps", nsteps, flush=True)
         ref.close()
     rem.close()
