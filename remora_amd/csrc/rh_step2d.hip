@@ -319,8 +319,13 @@ k2d_uvbar(B3 xb, B3 yb, B3 un, B3 rb, UVPar P, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, 
 // ghost faces from memory (ghost_from_mem); the valid faces are always rebuilt here.
 #define F_PX (RT_BX + 4)
 #define F_PY (U_BY + 4)
+#define F_N  (F_PX * F_PY)
 struct FTile { const double *s; int i0, j0; __device__ __forceinline__ double operator()(int i, int j, int) const { return s[(j - j0) * F_PX + (i - i0)]; } };
 enum { Q_ZN = Q_N, QF_N };
+enum { T_D, T_U, T_V, T_UB, T_VB, T_PM, T_PN, T_N };      // tiles: Drhs, DUon, DVom (rebuilt) ; ubar/vbar(krhs), pm, pn (staged)
+// One memory round trip per block: every global load of the kernel -- the tile points (two per thread) and this thread's own
+// operands of all later phases -- is issued up front; plain loads stay in flight across the barriers, so the LDS phases run
+// while the late operands are still arriving.  All stencil neighbours (ubar, vbar, pm, pn, Drhs, DUon, DVom) come from LDS.
 __global__ void __launch_bounds__(RT_BX * U_BY)
 k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, A4 vb_stp, A4 ub_new, A4 vb_new,
           A4 rubar_rhs, A4 rvbar_rhs, A4 rubar_stp, A4 rvbar_stp, A4 rubar_pts, A4 rvbar_pts,
@@ -330,47 +335,102 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
 {
     constexpr int NT = RT_BX * U_BY;
     __shared__ double lds[QF_N * NT];
-    static_assert(3 * F_PX * F_PY <= QF_N * NT, "tiles alias the flux slots");
+    static_assert(T_N * F_N <= QF_N * NT, "tiles alias the flux slots");
+    static_assert(F_N <= 2 * NT, "two tile points per thread");
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
     const RhTile rh_t_ = rh_tile();
     const int I0 = un.lo0 - 1 + rh_t_.x * U_SX, J0 = un.lo1 - 1 + rh_t_.y * U_SY;
     const int i = I0 + tx, j = J0 + ty;
-    double *tD = lds, *tU = lds + F_PX * F_PY, *tV = lds + 2 * F_PX * F_PY;
-    // ---- Drhs on the tile (advance_2d.cpp:149-152)
-    for (int t = tid; t < F_PX * F_PY; t += NT) {
-        const int y = t / F_PX, x = t - y * F_PX, gi = I0 - 2 + x, gj = J0 - 2 + y;
-        tD[t] = inb2(g3, gi, gj) ? zeta_rhs(gi, gj, 0) + h(gi, gj, 0) : 0.0;
-    }
-    __syncthreads();
-    // ---- DUon, DVom on the tile (:153-166)
-    for (int t = tid; t < F_PX * F_PY; t += NT) {
-        const int y = t / F_PX, x = t - y * F_PX, gi = I0 - 2 + x, gj = J0 - 2 + y;
-        double du = 0.0, dv = 0.0;
-        if (x >= 1 && inb2(xg, gi, gj)) {
-            if (ghost_from_mem && !inb2(xb, gi, gj)) du = DUon_g(gi, gj, 0);   // a ghost face: what FillBoundary left there
-            else {
-                const double on_u = 2.0 / (pn(gi, gj, 0) + pn(gi - 1, gj, 0));
-                const double cff1 = 0.5 * on_u * (tD[t] + tD[t - 1]);
-                du = ub_rhs(gi, gj, 0) * cff1;
-            }
-        }
-        if (y >= 1 && inb2(yg, gi, gj)) {
-            if (ghost_from_mem && !inb2(yb, gi, gj)) dv = DVom_g(gi, gj, 0);
-            else {
-                const double om_v = 2.0 / (pm(gi, gj, 0) + pm(gi, gj - 1, 0));
-                const double cff1 = 0.5 * om_v * (tD[t] + tD[t - F_PX]);
-                dv = vb_rhs(gi, gj, 0) * cff1;
-            }
-        }
-        tU[t] = du; tV[t] = dv;
-    }
-    __syncthreads();
-    const FTile Drhs{tD, I0 - 2, J0 - 2}, DUon{tU, I0 - 2, J0 - 2}, DVom{tV, I0 - 2, J0 - 2};
-    const bool in_rb = inb2(rb, i, j);
+    const bool in_rb = inb2(rb, i, j), in_un = inb2(un, i, j);
     const bool owner = in_rb && (tx >= 1 || rh_t_.x == 0) && (ty >= 1 || rh_t_.y == 0);
-    // ---- time averages (:293-356) and free surface (:379-464) on this thread's rho point
-    double zn0 = 0.0, zw0 = 0.0;
+    const bool is_u = tx >= 1 && ty <= U_BY - 2 && inb2(xb, i, j), is_v = tx <= RT_BX - 2 && ty >= 1 && inb2(yb, i, j);
+
+    // ---- (1) all global loads.  Tile points first: t = tid and tid + NT
+    double tz[2], th[2], tpm[2], tpn[2], tub[2], tvb[2], tdu[2], tdv[2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int t = tid + r * NT;
+        const int y = t / F_PX, x = t - y * F_PX, gi = I0 - 2 + x, gj = J0 - 2 + y;
+        const bool on = t < F_N;
+        const bool ing = on && inb2(g3, gi, gj);
+        tz[r] = ing ? zeta_rhs(gi, gj, 0) : 0.0; th[r] = ing ? h(gi, gj, 0) : 0.0;
+        tpm[r] = on ? ld_in(pm, gi, gj, 0) : 0.0; tpn[r] = on ? ld_in(pn, gi, gj, 0) : 0.0;
+        tub[r] = on ? ld_in(ub_rhs, gi, gj, 0) : 0.0; tvb[r] = on ? ld_in(vb_rhs, gi, gj, 0) : 0.0;
+        tdu[r] = 0.0; tdv[r] = 0.0;
+        if (ghost_from_mem && on) {                         // ghost faces: what FillBoundary left in memory
+            if (x >= 1 && inb2(xg, gi, gj) && !inb2(xb, gi, gj)) tdu[r] = DUon_g(gi, gj, 0);
+            if (y >= 1 && inb2(yg, gi, gj) && !inb2(yb, gi, gj)) tdv[r] = DVom_g(gi, gj, 0);
+        }
+    }
+    // this thread's own operands of the later phases
+    double h0 = 0, zr0 = 0, zs0 = 0, rS0 = 0, rA0 = 0, fc0 = 0, vr0 = 0, mr0 = 1.0, rzs = 0, rzp = 0, zt0 = 0, dua1 = 0, dua2 = 0, dva1 = 0, dva2 = 0;
     if (in_rb) {
+        h0 = h(i, j, 0); zr0 = zeta_rhs(i, j, 0); zs0 = zeta_stp(i, j, 0); rS0 = rhoS(i, j, 0); rA0 = rhoA(i, j, 0); vr0 = visc2_r(i, j, 0);
+        if (P.use_cor) fc0 = fcor(i, j, 0);
+        if (!zp.nomask) mr0 = mskr(i, j, 0);
+        if (zp.zmode == 2) { rzs = rzeta_stp(i, j, 0); rzp = rzeta_pts(i, j, 0); }
+        if (owner) {
+            if (zp.avg_mode == 1) { zt0 = Zt_avg1(i, j, 0); dua1 = DU_avg1(i, j, 0); dva1 = DV_avg1(i, j, 0); }
+            if (zp.avg_mode >= 1) { dua2 = DU_avg2(i, j, 0); dva2 = DV_avg2(i, j, 0); }
+        }
+    }
+    double vp0 = 0, mp0 = 1.0;
+    if (in_un) { vp0 = visc2_p(i, j, 0); if (!P.nomask) mp0 = mskp(i, j, 0); }
+    double u_frc = 0, u_r0 = 0, u_r1 = 0, u_stp = 0, u_rs = 0, u_rp = 0, u_msk = 1.0, u_zsw = 0;
+    if (is_u) {
+        u_frc = rufrc(i, j, 0); u_stp = ub_stp(i, j, 0); u_zsw = zeta_stp(i - 1, j, 0);
+        if (P.couple >= 2) u_r0 = ru2d(i, j, 0, 0);
+        if (P.couple == 3) u_r1 = ru2d(i, j, 0, 1);
+        if (P.am3) { u_rs = rubar_stp(i, j, 0); u_rp = rubar_pts(i, j, 0); }
+        if (!P.nomask) u_msk = msku(i, j, 0);
+    }
+    double v_frc = 0, v_r0 = 0, v_r1 = 0, v_stp = 0, v_rs = 0, v_rp = 0, v_msk = 1.0, v_zss = 0;
+    if (is_v) {
+        v_frc = rvfrc(i, j, 0); v_stp = vb_stp(i, j, 0); v_zss = zeta_stp(i, j - 1, 0);
+        if (P.couple >= 2) v_r0 = rv2d(i, j, 0, 0);
+        if (P.couple == 3) v_r1 = rv2d(i, j, 0, 1);
+        if (P.am3) { v_rs = rvbar_stp(i, j, 0); v_rp = rvbar_pts(i, j, 0); }
+        if (!P.nomask) v_msk = mskv(i, j, 0);
+    }
+
+    // ---- (2) staged tiles: Drhs (advance_2d.cpp:149-152), ubar / vbar(krhs), pm, pn
+    double *tl = lds;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int t = tid + r * NT;
+        if (t < F_N) {
+            tl[T_D * F_N + t] = tz[r] + th[r];
+            tl[T_UB * F_N + t] = tub[r]; tl[T_VB * F_N + t] = tvb[r]; tl[T_PM * F_N + t] = tpm[r]; tl[T_PN * F_N + t] = tpn[r];
+        }
+    }
+    __syncthreads();
+    // ---- (3) DUon, DVom on the tile (:153-166)
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int t = tid + r * NT;
+        if (t < F_N) {
+            const int y = t / F_PX, x = t - y * F_PX, gi = I0 - 2 + x, gj = J0 - 2 + y;
+            double du = tdu[r], dv = tdv[r];
+            if (x >= 1 && inb2(xg, gi, gj) && !(ghost_from_mem && !inb2(xb, gi, gj))) {
+                const double on_u = 2.0 / (tpn[r] + tl[T_PN * F_N + t - 1]);
+                const double cff1 = 0.5 * on_u * (tl[T_D * F_N + t] + tl[T_D * F_N + t - 1]);
+                du = tub[r] * cff1;
+            }
+            if (y >= 1 && inb2(yg, gi, gj) && !(ghost_from_mem && !inb2(yb, gi, gj))) {
+                const double om_v = 2.0 / (tpm[r] + tl[T_PM * F_N + t - F_PX]);
+                const double cff1 = 0.5 * om_v * (tl[T_D * F_N + t] + tl[T_D * F_N + t - F_PX]);
+                dv = tvb[r] * cff1;
+            }
+            tl[T_U * F_N + t] = du; tl[T_V * F_N + t] = dv;
+        }
+    }
+    __syncthreads();
+    const FTile Drhs{tl + T_D * F_N, I0 - 2, J0 - 2}, DUon{tl + T_U * F_N, I0 - 2, J0 - 2}, DVom{tl + T_V * F_N, I0 - 2, J0 - 2};
+    const FTile ubr{tl + T_UB * F_N, I0 - 2, J0 - 2}, vbr{tl + T_VB * F_N, I0 - 2, J0 - 2}, tpmv{tl + T_PM * F_N, I0 - 2, J0 - 2}, tpnv{tl + T_PN * F_N, I0 - 2, J0 - 2};
+    // ---- (4) time averages (:293-356) and free surface (:379-464) on this thread's rho point
+    double zn0 = 0.0, zw0 = 0.0, pm0 = 0.0, pn0 = 0.0;
+    if (in_rb) {
+        pm0 = tpmv(i, j, 0); pn0 = tpnv(i, j, 0);
         const double du0 = DUon(i, j, 0), dv0 = DVom(i, j, 0);
         if (owner) {
             if (zp.avg_mode == 0) {
@@ -378,64 +438,63 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
                 DU_avg1(i, j, 0) = 0.0; DU_avg2(i, j, 0) = zp.wt_b * du0;
                 DV_avg1(i, j, 0) = 0.0; DV_avg2(i, j, 0) = zp.wt_b * dv0;
             } else if (zp.avg_mode == 1) {
-                Zt_avg1(i, j, 0) += zp.wt_a * zeta_rhs(i, j, 0);
-                DU_avg1(i, j, 0) += zp.wt_a * du0; DU_avg2(i, j, 0) += zp.wt_b * du0;
-                DV_avg1(i, j, 0) += zp.wt_a * dv0; DV_avg2(i, j, 0) += zp.wt_b * dv0;
+                Zt_avg1(i, j, 0) = zt0 + zp.wt_a * zr0;
+                DU_avg1(i, j, 0) = dua1 + zp.wt_a * du0; DU_avg2(i, j, 0) = dua2 + zp.wt_b * du0;
+                DV_avg1(i, j, 0) = dva1 + zp.wt_a * dv0; DV_avg2(i, j, 0) = dva2 + zp.wt_b * dv0;
             } else {
-                DU_avg2(i, j, 0) = DU_avg2(i, j, 0) + zp.wt_b * du0;
-                DV_avg2(i, j, 0) = DV_avg2(i, j, 0) + zp.wt_b * dv0;
+                DU_avg2(i, j, 0) = dua2 + zp.wt_b * du0;
+                DV_avg2(i, j, 0) = dva2 + zp.wt_b * dv0;
             }
         }
         const double div = (du0 - DUon(i + 1, j, 0)) + (dv0 - DVom(i, j + 1, 0));
-        const double zs = zeta_stp(i, j, 0);
-        const double mr = zp.nomask ? 1.0 : mskr(i, j, 0);
+        const double zs = zs0, mr = mr0;
         if (zp.zmode == 0) {
             const double cff1 = zp.dtfast;
-            zn0 = (zs + pm(i, j, 0) * pn(i, j, 0) * cff1 * div) * mr;
+            zn0 = (zs + pm0 * pn0 * cff1 * div) * mr;
             zw0 = 0.5 * (zs + zn0);
         } else if (zp.zmode == 1) {
             const double cff1 = 2.0 * zp.dtfast, cff4 = 4.0 / 25.0, cff5 = 1.0 - 2.0 * cff4;
-            zn0 = (zs + pm(i, j, 0) * pn(i, j, 0) * cff1 * div) * mr;
-            zw0 = cff5 * zeta_rhs(i, j, 0) + cff4 * (zs + zn0);
+            zn0 = (zs + pm0 * pn0 * cff1 * div) * mr;
+            zw0 = cff5 * zr0 + cff4 * (zs + zn0);
         } else {
             const double cff1 = zp.dtfast * 5.0 / 12.0, cff2 = zp.dtfast * 8.0 / 12.0, cff3 = zp.dtfast * 1.0 / 12.0, cff4 = 2.0 / 5.0, cff5 = 1.0 - cff4;
             const double cff = cff1 * div;
-            zn0 = zs + pm(i, j, 0) * pn(i, j, 0) * (cff + cff2 * rzeta_stp(i, j, 0) - cff3 * rzeta_pts(i, j, 0));
+            zn0 = zs + pm0 * pn0 * (cff + cff2 * rzs - cff3 * rzp);
             zn0 *= mr;
-            zw0 = cff5 * zn0 + cff4 * zeta_rhs(i, j, 0);
+            zw0 = cff5 * zn0 + cff4 * zr0;
         }
         if (owner) {
             zeta_new(i, j, 0) = zn0;                                           // :450-454
             if (zp.predictor) rzeta_rhs(i, j, 0) = div;                        // :459-464
         }
     }
-    // ---- phase 1 of k2d_uvbar: the shared quantities of this thread's rho and psi point
+    // ---- (5) phase 1 of k2d_uvbar: the shared quantities of this thread's rho and psi point
     double *q = lds + tid;
     const double fac = 1000.0 / 1025.0;
-    double h0 = 0, rA0 = 0, pm0 = 0, pn0 = 0, gz0 = 0, gz20 = 0, gSA0 = 0;
+    double gz0 = 0, gz20 = 0, gSA0 = 0;
     double UFx = 0, VFe = 0, mUFx = 0, mVFe = 0, corU = 0, corV = 0, UFe = 0, VFx = 0, mUFe = 0, mVFx = 0;
     if (in_rb) {
-        h0 = h(i, j, 0); rA0 = rhoA(i, j, 0); pm0 = pm(i, j, 0); pn0 = pn(i, j, 0);
-        const double rS0 = rhoS(i, j, 0);
         gz0 = (fac + rS0) * zw0; gz20 = gz0 * zw0; gSA0 = zw0 * (rS0 - rA0);
-        UFx = s2_UFx(ub_rhs, DUon, i, j, P);
-        VFe = s2_VFe(vb_rhs, DVom, i, j, P);
-        const MixR r = mix_r_metrics(pm, pn, visc2_r, i, j);
-        const double cffr = mix_r_cff(r, Drhs, ub_rhs, vb_rhs, i, j, 0);
+        UFx = s2_UFx(ubr, DUon, i, j, P);
+        VFe = s2_VFe(vbr, DVom, i, j, P);
+        struct C0 { double v; __device__ __forceinline__ double operator()(int, int, int) const { return v; } };
+        const MixR r = mix_r_metrics(tpmv, tpnv, C0{vr0}, i, j);
+        const double cffr = mix_r_cff(r, Drhs, ubr, vbr, i, j, 0);
         mUFx = r.on_r * r.on_r * r.visc * cffr;
         mVFe = r.om_r * r.om_r * r.visc * cffr;
         if (P.use_cor) {
-            const double fm = fcor(i, j, 0) * (1.0 / (pm0 * pn0));
+            const double fm = fc0 * (1.0 / (pm0 * pn0));
             const double d = Drhs(i, j, 0);
-            corU = 0.5 * d * fm * (vb_rhs(i, j, 0) + vb_rhs(i, j + 1, 0));
-            corV = 0.5 * d * fm * (ub_rhs(i, j, 0) + ub_rhs(i + 1, j, 0));
+            corU = 0.5 * d * fm * (vbr(i, j, 0) + vbr(i, j + 1, 0));
+            corV = 0.5 * d * fm * (ubr(i, j, 0) + ubr(i + 1, j, 0));
         }
     }
-    if (inb2(un, i, j)) {
-        UFe = s2_UFe(ub_rhs, DVom, i, j, P);
-        VFx = s2_VFx(vb_rhs, DUon, i, j, P);
-        const MixP p = mix_p_metrics(pm, pn, visc2_p, MaskView{mskp, P.nomask}, i, j);
-        const double cffp = mix_p_cff(p, Drhs, ub_rhs, vb_rhs, i, j, 0);
+    if (in_un) {
+        UFe = s2_UFe(ubr, DVom, i, j, P);
+        VFx = s2_VFx(vbr, DUon, i, j, P);
+        struct C0 { double v; __device__ __forceinline__ double operator()(int, int, int) const { return v; } };
+        const MixP p = mix_p_metrics(tpmv, tpnv, C0{vp0}, C0{mp0}, i, j);
+        const double cffp = mix_p_cff(p, Drhs, ubr, vbr, i, j, 0);
         mUFe = p.om_p * p.om_p * p.visc * cffp;
         mVFx = p.on_p * p.on_p * p.visc * cffp;
     }
@@ -445,9 +504,9 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
     q[Q_PM * NT] = pm0; q[Q_PN * NT] = pn0; q[Q_UFE * NT] = UFe; q[Q_VFX * NT] = VFx; q[Q_MUFE * NT] = mUFe; q[Q_MVFX * NT] = mVFx;
     q[Q_ZN * NT] = zn0;
     __syncthreads();
-    // ---- phase 2 of k2d_uvbar
+    // ---- (6) phase 2 of k2d_uvbar
     const double cffg = 0.5 * P.g, third = 1.0 / 3.0;
-    if (tx >= 1 && ty <= U_BY - 2 && inb2(xb, i, j)) {
+    if (is_u) {
         const double *w = q - 1, *n = q + RT_BX;
         const double hx = w[Q_H * NT], zwx = w[Q_ZW * NT], rAx = w[Q_RA * NT], pmx = w[Q_PM * NT], pnx = w[Q_PN * NT];
         const double on_u = 2.0 / (pn0 + pnx);
@@ -466,34 +525,34 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
             const double cff2 = 0.5 * (pmx + pm0) * (n[Q_MUFE * NT] - mUFe);
             rhs += cff1 + cff2;
         }
-        if (P.couple == 0) rhs += rufrc(i, j, 0);
+        if (P.couple == 0) rhs += u_frc;
         else {
-            double f = rufrc(i, j, 0);
+            double f = u_frc;
             if (P.couple == 1) { f -= rhs; rhs += f; ru2d(i, j, 0, 0) = f; }
             else if (P.couple == 2) {
                 f = f - rhs;
-                const double r0 = ru2d(i, j, 0, 0);
+                const double r0 = u_r0;
                 rhs = rhs + 1.5 * f - 0.5 * r0;
                 ru2d(i, j, 0, 1) = r0; ru2d(i, j, 0, 0) = f;
             } else {
                 const double c1 = 23.0 / 12.0, c2 = 16.0 / 12.0, c3 = 5.0 / 12.0;
                 f = f - rhs;
-                const double r0 = ru2d(i, j, 0, 0), r1 = ru2d(i, j, 0, 1);
+                const double r0 = u_r0, r1 = u_r1;
                 rhs = rhs + c1 * f - c2 * r0 + c3 * r1;
                 ru2d(i, j, 0, 1) = r0; ru2d(i, j, 0, 0) = f;
             }
             rufrc(i, j, 0) = f;
         }
-        const double Dstp0 = zeta_stp(i, j, 0) + h0, Dstp1 = zeta_stp(i - 1, j, 0) + hx;
+        const double Dstp0 = zs0 + h0, Dstp1 = u_zsw + hx;
         const double cff = (pm0 + pmx) * (pn0 + pnx);
         const double Dnew_avg = 1.0 / ((zn0 + h0) + (w[Q_ZN * NT] + hx));
-        const double mu = P.nomask ? 1.0 : msku(i, j, 0);
-        if (!P.am3) ub_new(i, j, 0) = (ub_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mu;
-        else ub_new(i, j, 0) = (ub_stp(i, j, 0) * (Dstp0 + Dstp1) +
-                                cff * (P.c1 * rhs + P.c2 * rubar_stp(i, j, 0) - P.c3 * rubar_pts(i, j, 0))) * Dnew_avg * mu;
+        const double mu = u_msk;
+        if (!P.am3) ub_new(i, j, 0) = (u_stp * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mu;
+        else ub_new(i, j, 0) = (u_stp * (Dstp0 + Dstp1) +
+                                cff * (P.c1 * rhs + P.c2 * u_rs - P.c3 * u_rp)) * Dnew_avg * mu;
         if (P.predictor) rubar_rhs(i, j, 0) = rhs;
     }
-    if (tx <= RT_BX - 2 && ty >= 1 && inb2(yb, i, j)) {
+    if (is_v) {
         const double *sp = q - RT_BX, *e = q + 1;
         const double hy = sp[Q_H * NT], zwy = sp[Q_ZW * NT], rAy = sp[Q_RA * NT], pmy = sp[Q_PM * NT], pny = sp[Q_PN * NT];
         const double om_v = 2.0 / (pm0 + pmy);
@@ -512,31 +571,31 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
             const double cff2 = 0.5 * (pmy + pm0) * (mVFe - sp[Q_MVFE * NT]);
             rhs += cff1 - cff2;
         }
-        if (P.couple == 0) rhs += rvfrc(i, j, 0);
+        if (P.couple == 0) rhs += v_frc;
         else {
-            double f = rvfrc(i, j, 0);
+            double f = v_frc;
             if (P.couple == 1) { f -= rhs; rhs += f; rv2d(i, j, 0, 0) = f; }
             else if (P.couple == 2) {
                 f = f - rhs;
-                const double r0 = rv2d(i, j, 0, 0);
+                const double r0 = v_r0;
                 rhs = rhs + 1.5 * f - 0.5 * r0;
                 rv2d(i, j, 0, 1) = r0; rv2d(i, j, 0, 0) = f;
             } else {
                 const double c1 = 23.0 / 12.0, c2 = 16.0 / 12.0, c3 = 5.0 / 12.0;
                 f = f - rhs;
-                const double r0 = rv2d(i, j, 0, 0), r1 = rv2d(i, j, 0, 1);
+                const double r0 = v_r0, r1 = v_r1;
                 rhs = rhs + c1 * f - c2 * r0 + c3 * r1;
                 rv2d(i, j, 0, 1) = r0; rv2d(i, j, 0, 0) = f;
             }
             rvfrc(i, j, 0) = f;
         }
-        const double Dstp0 = zeta_stp(i, j, 0) + h0, Dstp1 = zeta_stp(i, j - 1, 0) + hy;
+        const double Dstp0 = zs0 + h0, Dstp1 = v_zss + hy;
         const double cff = (pm0 + pmy) * (pn0 + pny);
         const double Dnew_avg = 1.0 / ((zn0 + h0) + (sp[Q_ZN * NT] + hy));
-        const double mv = P.nomask ? 1.0 : mskv(i, j, 0);
-        if (!P.am3) vb_new(i, j, 0) = (vb_stp(i, j, 0) * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mv;
-        else vb_new(i, j, 0) = (vb_stp(i, j, 0) * (Dstp0 + Dstp1) +
-                                cff * (P.c1 * rhs + P.c2 * rvbar_stp(i, j, 0) - P.c3 * rvbar_pts(i, j, 0))) * Dnew_avg * mv;
+        const double mv = v_msk;
+        if (!P.am3) vb_new(i, j, 0) = (v_stp * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mv;
+        else vb_new(i, j, 0) = (v_stp * (Dstp0 + Dstp1) +
+                                cff * (P.c1 * rhs + P.c2 * v_rs - P.c3 * v_rp)) * Dnew_avg * mv;
         if (P.predictor) rvbar_rhs(i, j, 0) = rhs;
     }
 }
