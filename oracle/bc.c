@@ -8,6 +8,7 @@
  *     Source/BoundaryConditions/REMORA_PhysBCFunct.cpp:21-93, REMORA_BoundaryConditions_{cons,xvel,yvel,zvel}.cpp
  *   - BC table: Source/Initialization/REMORA_init_bcs.cpp:9-679
  */
+#define ORACLE_SERIAL_LOOPS
 #include <stdio.h>
 #include "oracle.h"
 

@@ -11,6 +11,7 @@
  *   baroclinic      TimeIntegration/REMORA_advance_3d_ml.cpp:6-71, REMORA_advance_3d.cpp:10-387
  *   plot variables  IO/REMORA_Plotfile.cpp:141-235 (cell-centred averages of face velocities)
  */
+#define ORACLE_SERIAL_LOOPS
 #include <stdio.h>
 #include "oracle.h"
 
@@ -233,8 +234,10 @@ static void init_smflux(OState *s,double time)
 }
 
 /* ------------------------------------------------------------------ create / init */
+int oracle_omp_threads = 1;     /* see fab.h: FORBOX / FORBOX2D */
 OState* o_create(const Params *prm)
 {
+    oracle_omp_threads = prm->threads > 1 ? prm->threads : 1;
     OState *s=(OState*)calloc(1,sizeof(OState));
     s->prm=*prm; const Params *P=&s->prm;
     s->nx=P->ncell[0]; s->ny=P->ncell[1]; s->nz=P->ncell[2]; s->N=s->nz-1;

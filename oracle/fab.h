@@ -72,12 +72,25 @@ static inline Fab fab_comp(Fab f,int n){ f.p+=f.sn*(long)n; f.nc-=n; return f; }
 #define V(f,i,j,k)      ((f).p[IX(f,i,j,k)])
 #define VN(f,i,j,k,n)   ((f).p[IX(f,i,j,k) + (long)(n)*(f).sn])
 
-/* loop over a box in the order amrex::ParallelFor uses on the CPU (k outer, i inner) */
+/* loop over a box in the order amrex::ParallelFor uses on the CPU (k outer, i inner).  Every such loop restates one
+ * amrex::ParallelFor pass, whose iterations are independent by contract (the same lambdas run as GPU kernels), so the j
+ * iterations of one level may be shared among OpenMP threads (k stays serial and outermost: some 3-D passes of this
+ * restatement accumulate over k into 2-D arrays).  oracle_omp_threads <= 1 (the default, and what every parity test uses)
+ * runs them serially in exactly this order; bench.py's cpu_baseline raises it (Params.threads) to time the path on all host
+ * cores, and tests/test_oracle_gold.py checks that the threaded run is bitwise the serial one. */
+extern int oracle_omp_threads;
+#ifdef ORACLE_SERIAL_LOOPS          /* bc.c, driver.c: ghost fills and glue whose loops may read what they write */
+#define ORACLE_PRAGMA(x)
+#else
+#define ORACLE_PRAGMA(x) _Pragma(#x)
+#endif
 #define FORBOX(b,i,j,k) \
     for(int k=(b).lo[2];k<=(b).hi[2];k++) \
+    ORACLE_PRAGMA(omp parallel for schedule(static) if(oracle_omp_threads > 1) num_threads(oracle_omp_threads > 1 ? oracle_omp_threads : 1)) \
     for(int j=(b).lo[1];j<=(b).hi[1];j++) \
     for(int i=(b).lo[0];i<=(b).hi[0];i++)
 #define FORBOX2D(b,i,j) \
+    ORACLE_PRAGMA(omp parallel for schedule(static) if(oracle_omp_threads > 1) num_threads(oracle_omp_threads > 1 ? oracle_omp_threads : 1)) \
     for(int j=(b).lo[1];j<=(b).hi[1];j++) \
     for(int i=(b).lo[0];i<=(b).hi[0];i++)
 

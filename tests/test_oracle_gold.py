@@ -57,3 +57,16 @@ def test_set_weights_properties(ndtfast):
     idx = np.arange(1, 2 * ndtfast + 2)
     assert abs((w1 * idx).sum() - ndtfast) < 1e-9 * ndtfast
     assert (w1[nfast:] == 0).all()
+
+
+def test_threaded_oracle_is_bitwise_the_serial_one():
+    """bench.py times the oracle with OpenMP threads over the leaf passes (oracle/fab.h: FORBOX); every parity test uses the
+    serial order.  Both must give the same bits."""
+    from remora_amd import cases
+    from oracle.oracle_py import Oracle
+    for name in ("Seamount", "DoubleGyre"):
+        cfg = cases.get(name)
+        a = Oracle(cfg); a.advance(3)
+        b = Oracle(cfg, threads=4); b.advance(3)
+        assert np.array_equal(a.plot(), b.plot()), name
+        a.close(); b.close()
