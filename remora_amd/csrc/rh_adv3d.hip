@@ -181,39 +181,42 @@ k_column_solver(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm
     extern __shared__ double vv_lds[];
     const int lane = threadIdx.x;
     double *sCF = vv_lds + lane, *sDC = vv_lds + (size_t)(N + 2) * 64 + lane;      // s[k * 64]
-    const RhTile rh_t_ = rh_tile();
-    const int i = bx.lo0 + rh_t_.x * 64 + lane, j = bx.lo1 + rh_t_.y;
-    const bool act = i <= bx.hi0;
-    const int ic = act ? i : bx.hi0;                       // inactive lanes shadow the last column (no stores)
-    const int ii = ic - IO, jj = j - JO;
-    const bool edge = (IO == 1) && (lane == 0);            // the only lane whose i-1 neighbour is not in the wave
+    // IO = 1 (u): waves overlap by one column -- lane 0 only carries Hz / Akv of the (i-1) neighbour of lane 1 into the shuffle, so no
+    // lane ever issues a one-element load.  JO = 1 (v): tiles are walked in 1 x 4 patches, so the row below (whose Hz / Akv this
+    // wave reads as its j-1 operands) is streamed by a wave of the same XCD at the same time and is found in that XCD's L2.
+    constexpr int SX = IO ? 63 : 64;
+    const RhTile rh_t_ = JO ? rh_tile_patch<1, 4>() : rh_tile();
+    const int i = bx.lo0 - IO + rh_t_.x * SX + lane, j = bx.lo1 + rh_t_.y;
+    const bool act = i <= bx.hi0 && !(IO && lane == 0);
+    const int ic = i <= bx.hi0 ? i : bx.hi0;               // lanes past the box shadow the last column (no stores)
+    const int ip = (IO && lane == 0) ? ic + 1 : ic;        // lane 0 of a u wave: phi / ru of its own column are never used; read lane 1's
+    const int jj = j - JO;
     const double sixth = 1.0 / 6.0, third = 1.0 / 3.0;
     // second point of the face average: (i-1,j) via shuffle, (i,j-1) via its own load, or the same point (tracers)
     auto second = [&](double own, double extra) -> double {
-        if (IO == 1) { const double s = __shfl_up(own, 1); return edge ? extra : s; }
+        if (IO == 1) return __shfl_up(own, 1);
         if (JO == 1) return extra;
         return own;
     };
     auto ld2 = [&](const A4 &a, int k) -> double {       // the load that `second` may need
-        if (IO == 1) return edge ? a(ic - 1, j, k) : 0.0;
         if (JO == 1) return a(ic, jj, k);
         return 0.0;
     };
     // k-invariant factor of the Adams-Bashforth term: cff * (pm + pm') * (pn + pn'), advance_3d.cpp:113-121
     double c2 = 0.0;
-    if (FULL) c2 = cab * (pm(ic, j, 0) + pm(ii, jj, 0)) * (pn(ic, j, 0) + pn(ii, jj, 0));
+    if (FULL) c2 = cab * (pm(ip, j, 0) + pm(ip - IO, jj, 0)) * (pn(ip, j, 0) + pn(ip - IO, jj, 0));
     auto start = [&](double u, double r, double hsum) -> double {     // the field the solve starts from
         if (!FULL) return u;
         double x = u; x += c2 * r; x *= 2.0 / hsum; return x;
     };
     auto load_f = [&](int k) -> ColLvl {                 // forward operands of level k: phi, Hz at k, Akv at k+1
         const int kc = k < N ? k : N;
-        ColLvl v; v.P = phi(ic, j, kc); v.R = FULL ? rphi(ic, j, kc) : 0.0; v.H = Hz(ic, j, kc); v.Hx = ld2(Hz, kc);
+        ColLvl v; v.P = phi(ip, j, kc); v.R = FULL ? rphi(ip, j, kc) : 0.0; v.H = Hz(ic, j, kc); v.Hx = ld2(Hz, kc);
         v.A = Akv(ic, j, kc + 1); v.Ax = ld2(Akv, kc + 1); return v;
     };
     auto load_b = [&](int k) -> ColLvl {                 // backward operands of level k
         const int kc = k > 0 ? k : 0;
-        ColLvl v; v.P = phi(ic, j, kc); v.R = FULL ? rphi(ic, j, kc) : 0.0; v.H = Hz(ic, j, kc); v.Hx = ld2(Hz, kc);
+        ColLvl v; v.P = phi(ip, j, kc); v.R = FULL ? rphi(ip, j, kc) : 0.0; v.H = Hz(ic, j, kc); v.Hx = ld2(Hz, kc);
         v.A = Akv(ic, j, kc); v.Ax = ld2(Akv, kc); return v;
     };
     // ---- upward elimination, vert_visc_3d.cpp:51-75
@@ -224,7 +227,7 @@ k_column_solver(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm
         Hzk_m = 0.5 * hs;
         AK_m = 0.5 * (second(a0, a0x) + a0);
         AK_0 = 0.5 * (second(a1, a1x) + a1);
-        phi_m = start(phi(ic, j, 0), FULL ? rphi(ic, j, 0) : 0.0, hs);
+        phi_m = start(phi(ip, j, 0), FULL ? rphi(ip, j, 0) : 0.0, hs);
     }
     double CFp = 0.0, DCp = 0.0, oHz_m = 1.0 / Hzk_m;
     auto fwd = [&](int k, const ColLvl &c) {              // level k of the elimination (all lanes: `second` shuffles)
@@ -294,15 +297,16 @@ k_column_solver(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm
     // ---- vert_mean_3d: ascending sums in the reference's order (:22-34), then the correction (:36-46)
     double CF = sCF[0], DCm = sDC[0] * CF;
     for (int k = 1; k <= N; k++) { const double Hzf = sCF[k * 64]; CF += Hzf; DCm += sDC[k * 64] * Hzf; }
-    const double on = 2.0 / (dxlen(ii, jj, 0) + dxlen(ic, j, 0));
+    const double on = 2.0 / (dxlen(ip - IO, jj, 0) + dxlen(ip, j, 0));
     const double cff1 = 1.0 / (CF * (on));
-    DCm = (DCm * (on) - Davg1(ic, j, 0)) * cff1;
-    const double m = msk(ic, j, 0);
+    DCm = (DCm * (on) - Davg1(ip, j, 0)) * cff1;
+    const double m = msk(ip, j, 0);
     if (act)
         for (int k = 0; k <= N; k++) { double x = sDC[k * 64]; x -= DCm; x *= m; phi(i, j, k) = x; }
 }
 #define VV_D_T 16      // ring depth, tracers (3 loads per level)
-#define VV_D_V 10      // ring depth, velocities (5-6 loads per level)
+#define VV_D_V 10      // ring depth, v (6 loads per level)
+#define VV_D_U 14      // ring depth, u (4 loads per level: the i-1 operands come from the neighbouring lane)
 
 extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 phi, rh_array4 Hz, rh_array4 Akv, int N, double dt)
 {
@@ -316,8 +320,9 @@ extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_
     const size_t lds_bytes = sizeof(double) * 2 * (size_t)(N + 2) * 64;
     if (!c->unfused && lds_bytes <= 64 * 1024) {         // coefficients in LDS (up to 62 levels at >= 2 wavefronts per CU)
         const dim3 grid((phi_bx.hi[0] - phi_bx.lo[0] + 64) / 64, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);
+        const dim3 gridu((phi_bx.hi[0] - phi_bx.lo[0] + 63) / 63, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);     // u waves overlap by one column
         const A4 z = mkA(phi);                           // unused operands of the FULL form
-        if (ioff) k_column_solver<1, 0, 0, VV_D_V><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
+        if (ioff) k_column_solver<1, 0, 0, VV_D_U><<<gridu, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
         else if (joff) k_column_solver<0, 1, 0, VV_D_V><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
         else k_column_solver<0, 0, 0, VV_D_T><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
     } else                                               // deeper columns: coefficients in the global work-space slab
@@ -344,9 +349,9 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     RH_NEED(s->Hz, xs); RH_NEED(s->Hz, ys); RH_NEED(s->Akv, xsw); RH_NEED(s->Akv, ysw);
     RH_NEED(s->pm, bx_slab(xs, 2, 0)); RH_NEED(s->pn, bx_slab(xs, 2, 0)); RH_NEED(s->pm, bx_slab(ys, 2, 0)); RH_NEED(s->pn, bx_slab(ys, 2, 0));
     RH_NEED(s->DU_avg1, bx_slab(xbx, 2, 0)); RH_NEED(s->DV_avg1, bx_slab(ybx, 2, 0)); RH_NEED(s->msku, bx_slab(xbx, 2, 0)); RH_NEED(s->mskv, bx_slab(ybx, 2, 0));
-    const dim3 gx((xbx.hi[0] - xbx.lo[0] + 64) / 64, xbx.hi[1] - xbx.lo[1] + 1, 1), gy((ybx.hi[0] - ybx.lo[0] + 64) / 64, ybx.hi[1] - ybx.lo[1] + 1, 1);
+    const dim3 gx((xbx.hi[0] - xbx.lo[0] + 63) / 63, xbx.hi[1] - xbx.lo[1] + 1, 1), gy((ybx.hi[0] - ybx.lo[0] + 64) / 64, ybx.hi[1] - ybx.lo[1] + 1, 1);
     { TScope t(c, "uv_corrector");
-    k_column_solver<1, 0, 1, VV_D_V><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn),
+    k_column_solver<1, 0, 1, VV_D_U><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn),
         mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab);
     RH_LAUNCH_CHECK(); }
     TScope t(c, "uv_corrector");
