@@ -35,28 +35,29 @@ __device__ __forceinline__ double a3_tflux_w(const A4 &t, int i, int j, int kk, 
 // reference evaluates cosh/exp at every (i,j,k).  sc = [sc_w | Cs_w | sc_r | Cs_r], each nz+1 long.
 __global__ void k_stretch(B3 b, A4 z_w, A4 z_r, A4 Hz, A4 h, A4 Zt, const double *__restrict__ sc, int nz, double hc)
 {
+    // one thread per (i,j,k): no level depends on another (each thread rebuilds the two faces of its cell with the expressions of
+    // the column loop, so the bits are the same), and a write-only kernel wants every lane storing at once
     RH_IJ(b); if (!inb2(b, i, j)) return;
+    const int k = RH_KZ;                                   // 0 .. nz-1
     const double *sc_w = sc, *Cs_w = sc + (nz + 1), *sc_r = sc + 2 * (nz + 1), *Cs_r = sc + 3 * (nz + 1);
     const double hwater = h(i, j, 0, 0);
     const double hinv = 1.0 / (hc + hwater);
     const double zt = Zt(i, j, 0);
-    double zw_prev = 0.0;
-    for (int k = 0; k <= nz; k++) {
-        const double cff_w = hc * sc_w[k], cff1_w = Cs_w[k];
+    auto face = [&](int kk) -> double {
+        const double cff_w = hc * sc_w[kk], cff1_w = Cs_w[kk];
         const double cff2_w = (cff_w + cff1_w * hwater) * hinv;
-        double zw;
-        if (k == nz) zw = zt;
-        else zw = zt + (zt + hwater) * cff2_w;
-        if (k == 0) h(i, j, 0, 1) = zw;
-        z_w(i, j, k) = zw;
-        if (k != nz) {
-            const double cff_r = hc * sc_r[k], cff1_r = Cs_r[k];
-            const double cff2_r = (cff_r + cff1_r * hwater) * hinv;
-            z_r(i, j, k) = zt + (zt + hwater) * cff2_r;
-        }
-        if (k > 0) Hz(i, j, k - 1) = zw - zw_prev;
-        zw_prev = zw;
+        return kk == nz ? zt : zt + (zt + hwater) * cff2_w;
+    };
+    const double zw0 = face(k), zw1 = face(k + 1);
+    if (k == 0) h(i, j, 0, 1) = zw0;
+    z_w(i, j, k) = zw0;
+    if (k == nz - 1) z_w(i, j, nz) = zw1;
+    {
+        const double cff_r = hc * sc_r[k], cff1_r = Cs_r[k];
+        const double cff2_r = (cff_r + cff1_r * hwater) * hinv;
+        z_r(i, j, k) = zt + (zt + hwater) * cff2_r;
     }
+    Hz(i, j, k) = zw1 - zw0;
 }
 extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
 {
@@ -68,7 +69,7 @@ extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
     RH_NEED(s->z_w, bw); RH_NEED(s->z_r, b); RH_NEED(s->Hz, b); RH_NEED(s->h, b2); RH_NEED(s->Zt_avg1, b2);
     if (s->h.ncomp < 2) return rh_fail("rh_stretch_transform: h needs 2 components");
     const double hc = -std::min(c->prm.prob_hi[2], -c->prm.tcline);                          // :51
-    k_stretch<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(s->z_w), mkA(s->z_r), mkA(s->Hz), mkA(s->h), mkA(s->Zt_avg1), c->d_sc, nz, hc);
+    k_stretch<<<grid3(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(s->z_w), mkA(s->z_r), mkA(s->Hz), mkA(s->h), mkA(s->Zt_avg1), c->d_sc, nz, hc);
     RH_LAUNCH_CHECK();
     BcScope xs(c);                                                                           // one message per neighbour for the three
     RH_TRY(halo_fill_boundary(c, mfv(c, s->z_w, 0, 0, 1), 0, 1));                            // :198-201
@@ -450,25 +451,28 @@ k_massflux_lds(B3 bx, A4 phi, A4 phibar, A4 Hphi, A4 Hz, A4 pmn, A4 Davg1, A4 Da
     extern __shared__ double mf_lds[];
     const int lane = threadIdx.x;
     double *sD = mf_lds + lane, *sX = mf_lds + (size_t)(N + 1) * 64 + lane;        // s[k * 64]
-    const RhTile rh_t_ = rh_tile();
-    const int i = bx.lo0 + rh_t_.x * 64 + lane, j = bx.lo1 + rh_t_.y;
-    const bool act = i <= bx.hi0;
-    const int ic = act ? i : bx.hi0;
-    const int ii = ic - IO, jj = j - JO;
-    const bool first = (IO == 1) && (lane == 0);
-    const double on = 2.0 / (pmn(ic, j, 0) + pmn(ii, jj, 0));
-    const bool edge = (ic == dlox - JO && !perx) || (ic == dhix + 1 && !perx) || (j == dloy - IO && !pery) || (j == dhiy + 1 && !pery);
+    // IO = 1: waves overlap by one column, lane 0 only carries Hz of the (i-1) neighbour of lane 1 into the shuffle; JO = 1: tiles in
+    // 1 x 4 patches, so the row below is streamed by a wave of the same XCD at the same time (see k_column_solver)
+    constexpr int SX = IO ? 63 : 64;
+    const RhTile rh_t_ = JO ? rh_tile_patch<1, 4>() : rh_tile();
+    const int i = bx.lo0 - IO + rh_t_.x * SX + lane, j = bx.lo1 + rh_t_.y;
+    const bool act = i <= bx.hi0 && !(IO && lane == 0);
+    const int ic = i <= bx.hi0 ? i : bx.hi0;
+    const int ip = (IO && lane == 0) ? ic + 1 : ic;        // lane 0 of a u wave: its own column is never used; shadow lane 1's
+    const int jj = j - JO;
+    const double on = 2.0 / (pmn(ip, j, 0) + pmn(ip - IO, jj, 0));
+    const bool edge = (ip == dlox - JO && !perx) || (ip == dhix + 1 && !perx) || (j == dloy - IO && !pery) || (j == dhiy + 1 && !pery);
     struct L { double p, f, h, hx; };
     auto load = [&](int k) -> L {
         const int kc = k < N ? k : N;
-        L r; r.p = phi(ic, j, kc); r.f = Hphi(ic, j, kc); r.h = Hz(ic, j, kc);
-        r.hx = (IO == 1) ? (first ? Hz(ic - 1, j, kc) : 0.0) : Hz(ic, jj, kc);
+        L r; r.p = phi(ip, j, kc); r.f = Hphi(ip, j, kc); r.h = Hz(ic, j, kc);
+        r.hx = (JO == 1) ? Hz(ic, jj, kc) : 0.0;
         return r;
     };
     double DCs = 0.0, CF = 0.0, FC = 0.0;
     auto step = [&](int k, const L &c) {
         double hx = c.hx;
-        if (IO == 1) { const double s = __shfl_up(c.h, 1); hx = first ? c.hx : s; }
+        if (IO == 1) hx = __shfl_up(c.h, 1);
         const double DCk = 0.5 * on * (c.h + hx);                     // :44-50
         DCs += DCk;
         CF += DCk * c.p;
@@ -491,19 +495,19 @@ k_massflux_lds(B3 bx, A4 phi, A4 phibar, A4 Hphi, A4 Hz, A4 pmn, A4 Davg1, A4 Da
 #pragma unroll
     for (int u = 0; u < D; u++) if (kb + u <= N) step(kb + u, ring[u]);
     const double DCi = 1.0 / DCs;
-    const double a1 = Davg1(ic, j, 0);
+    const double a1 = Davg1(ip, j, 0);
     CF = DCi * (CF - a1);
     if (edge) {                                                       // :87-101, then the flux sums again with the corrected velocity
-        const double m = msk(ic, j, 0);
+        const double m = msk(ip, j, 0);
         FC = 0.0;
         for (int k = 0; k <= N; k++) {
-            double x = phi(ic, j, k); x -= CF; x *= m;
+            double x = phi(ip, j, k); x -= CF; x *= m;
             if (act) phi(i, j, k) = x;
-            const double hp = 0.5 * (Hphi(ic, j, k) + x * sD[k * 64]);
+            const double hp = 0.5 * (Hphi(ip, j, k) + x * sD[k * 64]);
             sX[k * 64] = hp; FC += hp;
         }
     }
-    FC = DCi * (FC - Davg2(ic, j, 0));                                // :112-121
+    FC = DCi * (FC - Davg2(ip, j, 0));                                // :112-121
     if (act) {
         for (int k = 0; k <= N; k++) Hphi(i, j, k) = sX[k * 64] - sD[k * 64] * FC;
         const double pb = DCi * a1;
@@ -523,7 +527,8 @@ extern "C" int rh_update_massflux_3d(rh_ctx *c, rh_box bx, int ioff, int joff, r
     RH_NEED(phibar, b2); RH_NEED(Dphi_avg1, b2); RH_NEED(Dphi_avg2, b2); RH_NEED(msk, b2);
     const size_t lds_bytes = sizeof(double) * 2 * (size_t)(N + 1) * 64;
     if (!c->unfused && lds_bytes <= 64 * 1024) {
-        const dim3 grid((bx.hi[0] - bx.lo[0] + 64) / 64, bx.hi[1] - bx.lo[1] + 1, 1);
+        const int sx = ioff ? 63 : 64;                                 // u waves overlap by one column
+        const dim3 grid((bx.hi[0] - bx.lo[0] + sx) / sx, bx.hi[1] - bx.lo[1] + 1, 1);
 #define RH_MF(IO, JO) k_massflux_lds<IO, JO, MF_D><<<grid, 64, lds_bytes, c->stream>>>(mkB(bx), mkA(phi), mkA(phibar), mkA(Hphi), mkA(Hz), mkA(pm_or_pn), \
             mkA(Dphi_avg1), mkA(Dphi_avg2), mkA(msk), N, c->dom.lo[0], c->dom.hi[0], c->dom.lo[1], c->dom.hi[1], c->prm.periodic[0], c->prm.periodic[1])
         if (ioff) RH_MF(1, 0); else RH_MF(0, 1);

@@ -150,7 +150,7 @@ __global__ void k_omega(B3 b, A4 W, A4 Huon, A4 Hvom, A4 z_w, A4 h, int N)
 }
 // Same sweep with the running integral w(k) parked in LDS ([k][lane], one wavefront per block, one column per lane) instead of
 // being written to W and read back, and with the operands of level k+D requested while level k is integrated (register ring,
-// see k_column_solver in rh_adv3d.hip).  Huon(i+1) comes from the neighbouring lane; only the last lane loads it.
+// see k_column_solver in rh_adv3d.hip).  Huon(i+1) comes from the neighbouring lane.
 #define OM_D 12
 template <int D>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
@@ -159,20 +159,21 @@ k_omega_lds(B3 b, A4 W, A4 Huon, A4 Hvom, A4 z_w, A4 h, int N)
     extern __shared__ double om_lds[];
     const int lane = threadIdx.x;
     double *sW = om_lds + lane;                                       // sW[k * 64], k = 1 .. N+1
-    const RhTile rh_t_ = rh_tile();
-    const int i = b.lo0 + rh_t_.x * 64 + lane, j = b.lo1 + rh_t_.y;
-    const bool act = i <= b.hi0;
-    const int ic = act ? i : b.hi0;
-    const bool edge = (lane == 63) || (ic == b.hi0);                  // no in-wave neighbour holding Huon(i+1)
-    struct L { double u, ux, v0, v1; };
+    // waves overlap by one column: lane 63 only carries Huon(i+1) of lane 62 into the shuffle (no one-element loads); tiles are
+    // walked in 1 x 4 patches so that Hvom(j+1), the own row of the wave above, is found in the XCD's L2
+    const RhTile rh_t_ = rh_tile_patch<1, 4>();
+    const int i = b.lo0 + rh_t_.x * 63 + lane, j = b.lo1 + rh_t_.y;
+    const bool act = lane < 63 && i <= b.hi0;
+    const int ic = i <= b.hi0 ? i : b.hi0;
+    const int iu = i <= b.hi0 + 1 ? i : b.hi0 + 1;                    // Huon lives on the faces b.lo0 .. b.hi0 + 1
+    struct L { double u, v0, v1; };
     auto load = [&](int kk) -> L {                                    // level kk (clamped) of the fluxes
         const int kc = kk < N ? kk : N;
-        L r; r.u = Huon(ic, j, kc); r.ux = edge ? Huon(ic + 1, j, kc) : 0.0; r.v0 = Hvom(ic, j, kc); r.v1 = Hvom(ic, j + 1, kc); return r;
+        L r; r.u = Huon(iu, j, kc); r.v0 = Hvom(ic, j, kc); r.v1 = Hvom(ic, j + 1, kc); return r;
     };
     double w = 0.0;
     auto step = [&](int k, const L &c) {                              // :102-109: W(k) = W(k-1) - dHuon(k-1) - dHvom(k-1)
-        const double un = __shfl_down(c.u, 1);
-        const double up = edge ? c.ux : un;
+        const double up = __shfl_down(c.u, 1);
         w = w - (up - c.u) - (c.v1 - c.v0);
         sW[k * 64] = w;
     };
@@ -218,7 +219,7 @@ extern "C" int rh_omega(rh_ctx *c, rh_box gbx1, rh_array4 W, rh_array4 Huon, rh_
     RH_NEED(W, bw); RH_NEED(z_w, bw); RH_NEED(Huon, bx_nodal(b, 0)); RH_NEED(Hvom, bx_nodal(b, 1)); RH_NEED(h, bx_slab(b, 2, 0));
     const size_t lds_bytes = sizeof(double) * (size_t)(N + 2) * 64;
     if (!c->unfused && lds_bytes <= 64 * 1024) {
-        const dim3 grid((b.hi[0] - b.lo[0] + 64) / 64, b.hi[1] - b.lo[1] + 1, 1);
+        const dim3 grid((b.hi[0] - b.lo[0] + 63) / 63, b.hi[1] - b.lo[1] + 1, 1);     // waves overlap by one column
         k_omega_lds<OM_D><<<grid, 64, lds_bytes, c->stream>>>(mkB(b), mkA(W), mkA(Huon), mkA(Hvom), mkA(z_w), mkA(h), N);
     } else
         k_omega<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(W), mkA(Huon), mkA(Hvom), mkA(z_w), mkA(h), N);
