@@ -131,9 +131,17 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # REMORA_BENCH_TRANSPORT=host: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share cuda:0, messages are
+    # staged through the host over gloo).  Never the measured configuration: the driver's runs use RCCL, one GPU per rank.
+    host_transport = os.environ.get("REMORA_BENCH_TRANSPORT", "") == "host"
+    if host_transport:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if host_transport:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
 
     from remora_amd.model import REMORA
     px, py = (int(x) for x in a.grid.split("x")) if a.grid else (1, world)
@@ -145,7 +153,10 @@ def main():
     box = ((rx * a.nx, ry * a.ny, 0), ((rx + 1) * a.nx - 1, (ry + 1) * a.ny - 1, nz - 1))
     rem = REMORA(case, device=f"cuda:{local}", box=box, nranks=(px, py), rank_xy=(rx, ry))
     if world > 1:
-        rem.comm_init(dist)
+        if host_transport:
+            rem.comm_set_host_transport(dist)
+        else:
+            rem.comm_init(dist)
     rem.InitData()
 
     def barrier():
@@ -163,7 +174,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if host_transport else f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -199,7 +210,7 @@ def main():
                                       f"dt {case['fixed_dt']:.3f} s, ndtfast {case['ndtfast']}, nfast {rem.nfast}, "
                                       f"{f'{px}x{py} i-j decomposition, ghost exchange over RCCL' if world > 1 else 'single box'}",
                           "parallelism": f"ij-decomp {px}x{py}"},
-               "finite": finite,
+               "finite": finite, **({"transport": "host-staged gloo rehearsal (NOT the RCCL configuration)"} if host_transport else {}),
                "roofline": roof,
                "kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])},
                "algorithmic_hbm_frac_step": (1232.0 * cells_per_gpu / (el / a.steps)) / 1e9 / HBM_PEAK_GBS}
