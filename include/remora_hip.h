@@ -197,6 +197,16 @@ int  rh_advance_3d_ml(rh_ctx *ctx, rh_state *s, int istep);
 int  rh_advance(rh_ctx *ctx, rh_state *s, int istep, double t_old);
 void rh_swap_old_new(rh_state *s);
 
+/* ---- reductions around the step (REMORA::Evolve, Source/REMORA.cpp:139-212) ------------------------------ */
+/* REMORA::estTimeStep, TimeIntegration/REMORA_ComputeTimestep.cpp:39-95: max over the valid cells of |cell-centred velocity| / dx;
+ * *dt_out = fixed dt (rh_params.dt) if that is > 0, else cfl / max (1e20 if the max is not positive).  Across the ranks of the
+ * built-in RCCL communicator the max is all-reduced (ParallelDescriptor::ReduceRealMax, :66); local_only = 1 returns this rank's
+ * cfl / max for hosts that reduce with their own communicator.  Synchronises. */
+int  rh_est_timestep(rh_ctx *ctx, rh_state *s, double cfl, int local_only, double *dt_out);
+/* REMORA::sum_integrated_quantities + volWgtSumMF, Source/REMORA_SumIQ.cpp:9-141: out4 = { sum scalar*vol, sum kineng*vol, sum vol,
+ * max speed } with vol = Hz / (pm pn) and the ROMS kinetic energy of :38-40.  Sums across ranks as above.  Synchronises. */
+int  rh_sum_integrated_quantities(rh_ctx *ctx, rh_state *s, int local_only, double out4[4]);
+
 /* ---- synthetic initial state (outside the hot path; what InitData / prob.cpp provide in REMORA) ---- */
 /* Fills a bound native state for one of the pinned problems (0 Upwelling, 1 Seamount, 2 DoubleGyre, 3 Advection):
  * Source/REMORA.cpp:246-342,608-702, Initialization/REMORA_init.cpp, Exec/<case>/prob.cpp.  Synchronises. */

@@ -814,3 +814,32 @@ void o_plot(OState *s,int with_scalar,double *out)
     nc++; q=0;
     FORBOX(s->bx,i,j,k) out[nc*n3+(q++)]=0.5*(V(w,i,j,k)+V(w,i,j,k+1));
 }
+
+/* REMORA::estTimeStep, TimeIntegration/REMORA_ComputeTimestep.cpp:39-95: the cfl-limited dt from the cell-centred averages of the
+ * face velocities (amrex::average_face_to_cellcenter, then ReduceMax :52-66); returns cfl / max, 1e20 if the max is not positive */
+double o_est_timestep(OState *s,double cfl)
+{
+    const Params *P=&s->prm;
+    Fab u=F(xvel_new), v=F(yvel_new), w=F(zvel_new);
+    double dxi[3]={ s->nx/(P->prob_hi[0]-P->prob_lo[0]), s->ny/(P->prob_hi[1]-P->prob_lo[1]), s->nz/(P->prob_hi[2]-P->prob_lo[2]) };
+    double m=-1.e100;
+    FORBOX(s->bx,i,j,k){
+        double cu=0.5*(V(u,i,j,k)+V(u,i+1,j,k)), cv=0.5*(V(v,i,j,k)+V(v,i,j+1,k)), cw=0.5*(V(w,i,j,k)+V(w,i,j,k+1));
+        m=dmax(dmax(dmax(fabs(cu)*dxi[0],fabs(cv)*dxi[1]),fabs(cw)*dxi[2]),m);
+    }
+    return m>0.0 ? cfl/m : 1.e20;
+}
+/* REMORA::sum_integrated_quantities + volWgtSumMF, Source/REMORA_SumIQ.cpp:9-141: out = { scalar, kineng, volume, max_vel };
+ * the sums are MultiFab::Dot(tmp, volume) accumulated serially in FAB order (k, j, i) */
+void o_sum_iq(OState *s,double *out)
+{
+    Fab c=F(cons_new), u=F(xvel_new), v=F(yvel_new), Hz=F(Hz), pm=F(pm), pn=F(pn);
+    double scalar=0.0, kineng=0.0, volume=0.0, kemax=-1.e300;
+    FORBOX(s->bx,i,j,k){
+        double ke=0.25*(V(u,i,j,k)*V(u,i,j,k)+V(u,i+1,j,k)*V(u,i+1,j,k)+V(v,i,j,k)*V(v,i,j,k)+V(v,i,j+1,k)*V(v,i,j+1,k));
+        double vol=V(Hz,i,j,k)/(V(pm,i,j,0)*V(pn,i,j,0));
+        if(kemax<ke) kemax=ke;
+        scalar+=VN(c,i,j,k,2)*vol; kineng+=ke*vol; volume+=1.0*vol;
+    }
+    out[0]=scalar; out[1]=kineng; out[2]=volume; out[3]=sqrt(2.0*kemax);
+}

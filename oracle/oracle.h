@@ -111,5 +111,7 @@ int     o_istep(const OState*);
 int     o_field(OState*,const char *name,double **p,int lo[3],int hi[3],int *nc);
 /* plotfile variables (temp,salt,[scalar],x_velocity,y_velocity,z_velocity), FAB order, valid box */
 void    o_plot(OState*,int with_scalar,double *out);
+double  o_est_timestep(OState*,double cfl);
+void    o_sum_iq(OState*,double *out4);
 
 #endif

@@ -51,6 +51,10 @@ def lib():
         _lib.o_field.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.POINTER(C.c_double)), C.c_int * 3, C.c_int * 3,
                                  C.POINTER(C.c_int)]
         _lib.o_plot.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _lib.o_est_timestep.argtypes = [C.c_void_p, C.c_double]
+        _lib.o_est_timestep.restype = C.c_double
+        _lib.o_sum_iq.argtypes = [C.c_void_p, C.c_double * 4]
+        _lib.o_sum_iq.restype = None
         _lib.o_set_weights.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
     return _lib
 
@@ -127,6 +131,14 @@ class Oracle:
         out = np.empty((nc, nz, ny, nx))
         lib().o_plot(self.h, int(with_scalar), out.ctypes.data)
         return out
+
+    def est_timestep(self, cfl=0.8):
+        return float(lib().o_est_timestep(self.h, cfl))
+
+    def sum_iq(self):
+        out = (C.c_double * 4)()
+        lib().o_sum_iq(self.h, out)
+        return tuple(out)
 
 
 def set_weights(ndtfast):

@@ -19,6 +19,7 @@ int rccl_load()
     RH_SYM(GroupStart, "ncclGroupStart"); RH_SYM(GroupEnd, "ncclGroupEnd"); RH_SYM(Send, "ncclSend"); RH_SYM(Recv, "ncclRecv");
     RH_SYM(GetErrorString, "ncclGetErrorString");
 #undef RH_SYM
+    *(void **)(&g_rccl.AllReduce) = dlsym(h, "ncclAllReduce");          // only the diagnostics of rh_diag.hip use it
     g_rccl.handle = h;
     return 0;
 }

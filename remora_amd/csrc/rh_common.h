@@ -138,6 +138,7 @@ struct rh_ctx {
     // RCCL
     void *comm = nullptr; int rank = 0, nranks = 1;
     rh_exchange_fn xfn = nullptr; void *xuser = nullptr;      // transport of the ghost exchange (RCCL by default)
+    double *d_diag = nullptr;                                  // per-block partials of the diagnostics reductions (rh_diag.hip)
     double *d_xbuf = nullptr; long xcap = 0;                   // 4 message slots: send_lo, send_hi, recv_lo, recv_hi (xcap doubles each)
     // per-kernel-group timing
     bool timing = false;

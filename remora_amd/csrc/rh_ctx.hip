@@ -334,7 +334,7 @@ extern "C" int rh_destroy(rh_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (auto &v : c->tev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &e : c->evpool) (void)hipEventDestroy(e);
-    (void)hipFree(c->d_sc); (void)hipFree(c->d_work); if (c->d_xbuf) (void)hipFree(c->d_xbuf);
+    (void)hipFree(c->d_sc); (void)hipFree(c->d_work); if (c->d_xbuf) (void)hipFree(c->d_xbuf); if (c->d_diag) (void)hipFree(c->d_diag);
     comm_release(c);
     delete c;
     return 0;

@@ -232,6 +232,19 @@ class REMORA:
         self.sync()
         return out.cpu().numpy()
 
+    # ---- reductions around the step ------------------------------------------------------------------------
+    def estTimeStep(self, cfl=0.8, local_only=False):
+        """REMORA::estTimeStep (REMORA_ComputeTimestep.cpp:39-95)."""
+        dt = C.c_double()
+        L.check(self.lib.rh_est_timestep(self.ctx, C.byref(self.state), cfl, int(local_only), C.byref(dt)))
+        return dt.value
+
+    def sum_integrated_quantities(self, local_only=False):
+        """REMORA::sum_integrated_quantities (REMORA_SumIQ.cpp:9-106): (scalar, kineng, volume, max_vel)."""
+        out = (C.c_double * 4)()
+        L.check(self.lib.rh_sum_integrated_quantities(self.ctx, C.byref(self.state), int(local_only), out))
+        return tuple(out)
+
     # ---- per-kernel timing ---------------------------------------------------------------------------------
     def timing(self, on=True):
         L.check(self.lib.rh_timing_enable(self.ctx, int(on)))

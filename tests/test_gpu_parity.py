@@ -135,3 +135,31 @@ def test_rccl_transport_selftest():
     L.check(rem.lib.rh_comm_init(rem.ctx, idbuf, 0, 1))
     L.check(rem.lib.rh_comm_selftest(rem.ctx, 100000))
     rem.close()
+
+
+@pytest.mark.parametrize("case", ["Seamount", "DoubleGyre", "Advection"])
+def test_reductions_against_oracle(case):
+    """estTimeStep (REMORA_ComputeTimestep.cpp:39-95) and sum_integrated_quantities (REMORA_SumIQ.cpp:9-141) after five steps from
+    the same state.  Maxima (the cfl dt, the maximum speed) are order-independent: bit-identical.  The three volume-weighted sums
+    are folded in another order than the reference's serial MultiFab::Dot: relative 1e-13 (about n * eps / sqrt(n) of the
+    2e4..1e5 cells of these cases, with margin)."""
+    cfg = cases.get(case)
+    orc = Oracle(cfg)
+    rem = REMORA(cfg, device="cuda:0")
+    upload_oracle_state(orc, rem)
+    for _ in range(5):
+        orc.advance(1); rem.timeStep()
+    if case in BITEXACT:
+        assert rem.estTimeStep(0.8, local_only=True) == orc.est_timestep(0.8)
+    else:
+        assert abs(rem.estTimeStep(0.8, local_only=True) / orc.est_timestep(0.8) - 1.0) < 1e-12
+    assert rem.estTimeStep(0.8) == cfg["fixed_dt"]                    # fixed_dt wins (:90-91)
+    a = rem.sum_integrated_quantities(); b = orc.sum_iq()
+    rtol = 1e-13 if case in BITEXACT else 1e-11          # Advection: the fields themselves differ by the device exp() (see the module docstring)
+    for x, y, name in zip(a[:3], b[:3], ("scalar", "kineng", "volume")):
+        assert abs(x - y) <= rtol * max(abs(y), 1e-300) or abs(x - y) < 1e-300, (name, x, y)
+    if case in BITEXACT:
+        assert a[3] == b[3]
+    else:
+        assert abs(a[3] - b[3]) <= 1e-12 * abs(b[3])
+    rem.close(); orc.close()
