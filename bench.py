@@ -80,17 +80,23 @@ def parse():
     ap.add_argument("--nx", type=int, default=2048)
     ap.add_argument("--ny", type=int, default=2048, help="cells in j PER GPU")
     ap.add_argument("--nz", type=int, default=50)
+    ap.add_argument("--case", type=str, default="DoubleGyre", help="physics of the synthetic grid: DoubleGyre (BASELINE configs[3], the measured workload) or "
+                    "Upwelling (configs[4]-shaped blocks, e.g. --case Upwelling --nx 4096 --ny 2048 --nz 64)")
     ap.add_argument("--grid", type=str, default="", help="process grid PXxPY (PX * PY = --gpus); default 1xN = j-slabs, every rank keeps full 512-B-coalesced i rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="256x256x50x3", help="nx x ny x nz x steps of the CPU-oracle sample")
     return ap.parse_args()
 
 
-def bench_case(nx_per_gpu, ny_per_gpu, nz, px, py=None):
+def bench_case(nx_per_gpu, ny_per_gpu, nz, px, py=None, name="DoubleGyre"):
     from remora_amd import cases
     if py is None:
         px, py = 1, px
-    c = cases.get("DoubleGyre")
+    c = cases.get(name)
+    if name == "Upwelling":            # dx = dy = 1 km as in the reference input (its bathymetry depends on the j index and on dx)
+        c["prob_hi"] = (1000.0 * nx_per_gpu * px, 1000.0 * ny_per_gpu * py, 0.0)
+        c["ncell"] = (nx_per_gpu * px, ny_per_gpu * py, nz)
+        return c
     base = c["ncell"]
     nx, ny = nx_per_gpu * px, ny_per_gpu * py
     # the physical extent grows with the process grid so dx, dy (and the work per GPU) are fixed
@@ -148,7 +154,7 @@ def main():
     if px * py != world:
         raise SystemExit(f"--grid {a.grid} does not match {world} ranks")
     rx, ry = rank % px, rank // px
-    case = bench_case(a.nx, a.ny, a.nz, px, py)
+    case = bench_case(a.nx, a.ny, a.nz, px, py, a.case)
     nx, ny, nz = case["ncell"]
     box = ((rx * a.nx, ry * a.ny, 0), ((rx + 1) * a.nx - 1, (ry + 1) * a.ny - 1, nz - 1))
     rem = REMORA(case, device=f"cuda:{local}", box=box, nranks=(px, py), rank_xy=(rx, ry))
@@ -206,7 +212,7 @@ def main():
         out = {"metric": "3D baroclinic cell-updates/s", "value": cells_per_gpu * world * a.steps / el, "unit": "cell-updates/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": f"DoubleGyre physics, {a.nx}x{a.ny}x{nz} cells per GPU (domain {nx}x{ny}x{nz}), "
+               "config": {"workload": f"{a.case} physics, {a.nx}x{a.ny}x{nz} cells per GPU (domain {nx}x{ny}x{nz}), "
                                       f"dt {case['fixed_dt']:.3f} s, ndtfast {case['ndtfast']}, nfast {rem.nfast}, "
                                       f"{f'{px}x{py} i-j decomposition, ghost exchange over RCCL' if world > 1 else 'single box'}",
                           "parallelism": f"ij-decomp {px}x{py}"},

@@ -319,7 +319,9 @@ extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_
     rh_box pw = phi_bx; pw.hi[2] = N + 1;
     RH_NEED(phi, phi_bx); RH_NEED(Hz, bs); RH_NEED(Akv, bw); RH_NEED(c->wCF, pw); RH_NEED(c->wDC, pw);
     const size_t lds_bytes = sizeof(double) * 2 * (size_t)(N + 2) * 64;
-    if (!c->unfused && lds_bytes <= 64 * 1024) {         // coefficients in LDS (up to 62 levels at >= 2 wavefronts per CU)
+    if (!c->unfused && lds_bytes <= RH_LDS_MAX) {        // coefficients in LDS (up to 78 levels at >= 2 wavefronts per CU)
+        RH_HIP(rh_lds_optin(k_column_solver<1, 0, 0, VV_D_U>, lds_bytes)); RH_HIP(rh_lds_optin(k_column_solver<0, 1, 0, VV_D_V>, lds_bytes));
+        RH_HIP(rh_lds_optin(k_column_solver<0, 0, 0, VV_D_T>, lds_bytes));
         const dim3 grid((phi_bx.hi[0] - phi_bx.lo[0] + 64) / 64, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);
         const dim3 gridu((phi_bx.hi[0] - phi_bx.lo[0] + 63) / 63, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);     // u waves overlap by one column
         const A4 z = mkA(phi);                           // unused operands of the FULL form
@@ -338,7 +340,8 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     const int N = c->N; const double dt = c->prm.dt;
     const size_t lds_bytes = sizeof(double) * 2 * (size_t)(N + 2) * 64;
     *applied = 0;
-    if (c->unfused || lds_bytes > 64 * 1024) return 0;
+    if (c->unfused || lds_bytes > RH_LDS_MAX) return 0;
+    RH_HIP(rh_lds_optin(k_column_solver<1, 0, 1, VV_D_U>, lds_bytes)); RH_HIP(rh_lds_optin(k_column_solver<0, 1, 1, VV_D_V>, lds_bytes));
     const int iic = istep, ntfirst = 0;
     double cab;
     if (iic == ntfirst) cab = 0.25 * dt; else if (iic == ntfirst + 1) cab = 0.25 * dt * 3.0 / 2.0; else cab = 0.25 * dt * 23.0 / 12.0;
@@ -526,7 +529,8 @@ extern "C" int rh_update_massflux_3d(rh_ctx *c, rh_box bx, int ioff, int joff, r
     RH_NEED(phi, bx); RH_NEED(Hphi, bx); RH_NEED(Hz, bs); RH_NEED(pm_or_pn, bx_slab(bs, 2, 0));
     RH_NEED(phibar, b2); RH_NEED(Dphi_avg1, b2); RH_NEED(Dphi_avg2, b2); RH_NEED(msk, b2);
     const size_t lds_bytes = sizeof(double) * 2 * (size_t)(N + 1) * 64;
-    if (!c->unfused && lds_bytes <= 64 * 1024) {
+    if (!c->unfused && lds_bytes <= RH_LDS_MAX) {
+        RH_HIP(rh_lds_optin(k_massflux_lds<1, 0, MF_D>, lds_bytes)); RH_HIP(rh_lds_optin(k_massflux_lds<0, 1, MF_D>, lds_bytes));
         const int sx = ioff ? 63 : 64;                                 // u waves overlap by one column
         const dim3 grid((bx.hi[0] - bx.lo[0] + sx) / sx, bx.hi[1] - bx.lo[1] + 1, 1);
 #define RH_MF(IO, JO) k_massflux_lds<IO, JO, MF_D><<<grid, 64, lds_bytes, c->stream>>>(mkB(bx), mkA(phi), mkA(phibar), mkA(Hphi), mkA(Hz), mkA(pm_or_pn), \

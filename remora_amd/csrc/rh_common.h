@@ -104,6 +104,14 @@ __device__ __forceinline__ RhTile rh_tile_patch()
 #define RH_IJ(b) const RhTile rh_t_ = rh_tile(); const int i = (b).lo0 + rh_t_.x * RH_BX + (int)threadIdx.x; const int j = (b).lo1 + rh_t_.y * RH_BY + (int)threadIdx.y
 #define RH_KZ rh_t_.z      /* grid.z index of a pointwise 3-D kernel (after RH_IJ) */
 
+// Dynamic LDS of the one-wavefront column kernels.  Up to 64 KB needs no opt-in; above that (deep columns: nz >= 63 for the
+// tridiagonal solver) the kernel is raised to what it asks for, up to half the CU's 160 KB so that two wavefronts still share a CU.
+#define RH_LDS_MAX (80 * 1024)
+template <class K> static inline hipError_t rh_lds_optin(K kernel, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 extern thread_local std::string g_rh_err;
 int rh_fail(const char *fmt, ...);
 #define RH_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return rh_fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)

@@ -218,7 +218,8 @@ extern "C" int rh_omega(rh_ctx *c, rh_box gbx1, rh_array4 W, rh_array4 Huon, rh_
     rh_box b = gbx1; b.lo[2] = 0; b.hi[2] = N; rh_box bw = b; bw.hi[2] = N + 1;
     RH_NEED(W, bw); RH_NEED(z_w, bw); RH_NEED(Huon, bx_nodal(b, 0)); RH_NEED(Hvom, bx_nodal(b, 1)); RH_NEED(h, bx_slab(b, 2, 0));
     const size_t lds_bytes = sizeof(double) * (size_t)(N + 2) * 64;
-    if (!c->unfused && lds_bytes <= 64 * 1024) {
+    if (!c->unfused && lds_bytes <= RH_LDS_MAX) {
+        RH_HIP(rh_lds_optin(k_omega_lds<OM_D>, lds_bytes));
         const dim3 grid((b.hi[0] - b.lo[0] + 63) / 63, b.hi[1] - b.lo[1] + 1, 1);     // waves overlap by one column
         k_omega_lds<OM_D><<<grid, 64, lds_bytes, c->stream>>>(mkB(b), mkA(W), mkA(Huon), mkA(Hvom), mkA(z_w), mkA(h), N);
     } else
