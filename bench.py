@@ -43,7 +43,7 @@ ALGO_DOUBLES = {
 # kernel(s) behind each group in the rocprofv3 output (profiles/*_traffic.json keys start with these)
 GROUP_KERNELS = {
     "prestep_t3": ["k_tracers_tiled<0"], "rhs_t3": ["k_tracers_tiled<1"], "rhs_uv_3d": ["k_rhs_uv_tiled"], "uv3dmix": ["k_uv3dmix_tiled"],
-    "uv_corrector": ["k_column_solver<1, 0, 1", "k_column_solver<0, 1, 1"], "vert_visc_3d": ["k_column_solver<0, 0, 0"],
+    "uv_corrector": ["k_column_solver_reg<1, 0, 1", "k_column_solver_reg<0, 1, 1"], "vert_visc_3d": ["k_column_solver_reg<0, 0, 0"],
     "update_massflux_3d": ["k_massflux_lds"], "prsgrd": ["k_prsgrd_P", "k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos"], "omega": ["k_omega_lds"],
     "prestep_uv": ["k_prestep_uv"], "stretch_transform": ["k_stretch"], "vmix": ["k_vmix"], "massflux_old": ["k_massflux_old"],
 }

@@ -305,6 +305,119 @@ k_column_solver(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm
     if (act)
         for (int k = 0; k <= N; k++) { double x = sDC[k * 64]; x -= DCm; x *= m; phi(i, j, k) = x; }
 }
+// ---- the same solver with NO second read of its operands, for columns of up to VV_NZMAX levels.  The elimination coefficients
+// CF(k), DC(k) and the face-averaged AK(k) stay in REGISTERS (the loops over k are fully unrolled, so every index is a compile-time
+// constant; one wavefront per SIMD owns the whole 512-entry register file), the field the solve starts from and Hzk(k) are parked
+// in LDS ([k][lane]).  The back-substitution then touches no global memory: each operand travels HBM -> CU exactly once
+// (k_column_solver re-reads 3..6 arrays on the way down: 1.8-2.7x the algorithmic bytes, profiles/r1_v5_traffic.json).
+// Same expressions in the same order as k_column_solver: bit-identical.
+// The number of levels is a template parameter: with a run-time trip count every unrolled level becomes a guarded block, and the
+// wait counts hipcc then places at the joins drain the load ring (measured: 1.7x slower than the ring kernel).  Instantiated for
+// the depths of the pinned cases and of the roofline configuration; any other depth takes k_column_solver.
+template <int IO, int JO, int FULL, int D, int NZ>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm, A4 pn, A4 msk, int /*N*/, double dt, double cab)
+{
+    constexpr int N = NZ - 1, VV_NZMAX = NZ;
+    extern __shared__ double vv_lds[];
+    const int lane = threadIdx.x;
+    double *sX = vv_lds + lane, *sH = vv_lds + (size_t)(N + 1) * 64 + lane;        // s[k * 64], k = 0 .. N
+    constexpr int SX = IO ? 63 : 64;
+    const RhTile rh_t_ = JO ? rh_tile_patch<1, 4>() : rh_tile();
+    const int i = bx.lo0 - IO + rh_t_.x * SX + lane, j = bx.lo1 + rh_t_.y;
+    const bool act = i <= bx.hi0 && !(IO && lane == 0);
+    const int ic = i <= bx.hi0 ? i : bx.hi0;
+    const int ip = (IO && lane == 0) ? ic + 1 : ic;
+    const int jj = j - JO;
+    const double sixth = 1.0 / 6.0, third = 1.0 / 3.0;
+    auto second = [&](double own, double extra) -> double {
+        if (IO == 1) return __shfl_up(own, 1);
+        if (JO == 1) return extra;
+        return own;
+    };
+    auto ld2 = [&](const A4 &a, int k) -> double { if (JO == 1) return a(ic, jj, k); return 0.0; };
+    double c2 = 0.0;
+    if (FULL) c2 = cab * (pm(ip, j, 0) + pm(ip - IO, jj, 0)) * (pn(ip, j, 0) + pn(ip - IO, jj, 0));
+    auto start = [&](double u, double r, double hsum) -> double {
+        if (!FULL) return u;
+        double x = u; x += c2 * r; x *= 2.0 / hsum; return x;
+    };
+    auto load_f = [&](int k) -> ColLvl {
+        const int kc = k < N ? k : N;
+        ColLvl v; v.P = phi(ip, j, kc); v.R = FULL ? rphi(ip, j, kc) : 0.0; v.H = Hz(ic, j, kc); v.Hx = ld2(Hz, kc);
+        v.A = Akv(ic, j, kc + 1); v.Ax = ld2(Akv, kc + 1); return v;
+    };
+    double cf[VV_NZMAX], dc[VV_NZMAX], ak[VV_NZMAX];
+    double Hzk_m, AK_m, AK_0, phi_m;
+    {
+        const double h = Hz(ic, j, 0), hx = ld2(Hz, 0), a0 = Akv(ic, j, 0), a0x = ld2(Akv, 0), a1 = Akv(ic, j, 1), a1x = ld2(Akv, 1);
+        const double hs = second(h, hx) + h;
+        Hzk_m = 0.5 * hs;
+        AK_m = 0.5 * (second(a0, a0x) + a0);
+        AK_0 = 0.5 * (second(a1, a1x) + a1);
+        phi_m = start(phi(ip, j, 0), FULL ? rphi(ip, j, 0) : 0.0, hs);
+    }
+    ak[0] = AK_m; cf[0] = 0.0; dc[0] = 0.0;
+    sX[0] = phi_m; sH[0] = Hzk_m;
+    double CFp = 0.0, DCp = 0.0, oHz_m = 1.0 / Hzk_m;
+    ColLvl ring[D];
+#pragma unroll
+    for (int u = 0; u < D; u++) ring[u] = load_f(1 + u);
+    // ---- upward elimination, vert_visc_3d.cpp:51-75
+#pragma clang loop unroll(full)
+    for (int k = 1; k < VV_NZMAX; k++) {
+        {
+        const ColLvl c = ring[(k - 1) % D];
+        const double hs = second(c.H, c.Hx) + c.H;
+        const double Hzk_0 = 0.5 * hs;
+        const double AK_p = 0.5 * (second(c.A, c.Ax) + c.A);
+        const double phi_0 = start(c.P, c.R, hs);
+        const double oHzkm1 = oHz_m;
+        const double oHz = 1.0 / Hzk_0;
+        const double FC = sixth * Hzk_m - dt * AK_m / Hzk_m;
+        double CF = sixth * Hzk_0 - dt * AK_p / Hzk_0;
+        const double BC = third * (Hzk_m + Hzk_0) + dt * AK_0 * (oHzkm1 + oHz);
+        const double cff = 1.0 / (BC - FC * CFp);
+        CF *= cff;
+        const double DC = cff * (phi_0 - phi_m - FC * DCp);
+        cf[k] = CF; dc[k] = DC; ak[k] = AK_0;
+        sX[k * 64] = phi_0; sH[k * 64] = Hzk_0;
+        __builtin_amdgcn_sched_barrier(0);
+        ring[(k - 1) % D] = load_f(k + D);
+        double carry = phi_0; asm volatile("" : "+v"(carry));
+        CFp = CF; DCp = DC; Hzk_m = Hzk_0; AK_m = AK_0; AK_0 = AK_p; phi_m = carry; oHz_m = oHz;
+        }
+    }
+    // ---- back-substitution fused with the update, :81-106.  Here AK_0 = AK(N+1).  No global loads.
+    double DC_up = 0.0, DCs_up = DC_up * AK_0;
+#pragma clang loop unroll(full)
+    for (int k = VV_NZMAX - 1; k >= 0; k--) {
+        {
+            double DC;
+            if (k >= 1) { DC = dc[k]; DC -= cf[k] * DC_up; }
+            else DC = 0.0;
+            const double DCs = DC * ak[k];
+            const double Hzk = sH[k * 64];
+            const double oHz = 1.0 / Hzk;
+            const double cff = dt * oHz * (DCs_up - DCs);
+            const double x = sX[k * 64] + cff;
+            if (FULL) sX[k * 64] = x;
+            else if (act) phi(i, j, k) = x;
+            DC_up = DC; DCs_up = DCs;
+        }
+    }
+    if (!FULL) return;
+    // ---- vert_mean_3d: ascending sums in the reference's order (:22-34), then the correction (:36-46)
+    double CF = sH[0], DCm = sX[0] * CF;
+    for (int k = 1; k <= N; k++) { const double Hzf = sH[k * 64]; CF += Hzf; DCm += sX[k * 64] * Hzf; }
+    const double on = 2.0 / (dxlen(ip - IO, jj, 0) + dxlen(ip, j, 0));
+    const double cff1 = 1.0 / (CF * (on));
+    DCm = (DCm * (on) - Davg1(ip, j, 0)) * cff1;
+    const double m = msk(ip, j, 0);
+    if (act)
+        for (int k = 0; k <= N; k++) { double x = sX[k * 64]; x -= DCm; x *= m; phi(i, j, k) = x; }
+}
+static inline bool vv_reg_depth(int nz) { return nz == 13 || nz == 16 || nz == 50; }
 #define VV_D_T 16      // ring depth, tracers (3 loads per level)
 #define VV_D_V 10      // ring depth, v (6 loads per level)
 #define VV_D_U 14      // ring depth, u (4 loads per level: the i-1 operands come from the neighbouring lane)
@@ -325,7 +438,16 @@ extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_
         const dim3 grid((phi_bx.hi[0] - phi_bx.lo[0] + 64) / 64, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);
         const dim3 gridu((phi_bx.hi[0] - phi_bx.lo[0] + 63) / 63, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);     // u waves overlap by one column
         const A4 z = mkA(phi);                           // unused operands of the FULL form
-        if (ioff) k_column_solver<1, 0, 0, VV_D_U><<<gridu, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
+        const size_t lds_reg = sizeof(double) * 2 * (size_t)(N + 1) * 64;
+        if (vv_reg_depth(N + 1) && !c->noregsolve) {     // a depth the register form is built for: no operand is read twice
+#define RH_VVR(NZ) do { \
+            if (ioff) k_column_solver_reg<1, 0, 0, VV_D_U, NZ><<<gridu, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); \
+            else if (joff) k_column_solver_reg<0, 1, 0, VV_D_V, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); \
+            else k_column_solver_reg<0, 0, 0, VV_D_T, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); } while (0)
+            switch (N + 1) { case 13: RH_VVR(13); break; case 16: RH_VVR(16); break; default: RH_VVR(50); break; }
+#undef RH_VVR
+        }
+        else if (ioff) k_column_solver<1, 0, 0, VV_D_U><<<gridu, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
         else if (joff) k_column_solver<0, 1, 0, VV_D_V><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
         else k_column_solver<0, 0, 0, VV_D_T><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
     } else                                               // deeper columns: coefficients in the global work-space slab
@@ -354,12 +476,20 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     RH_NEED(s->pm, bx_slab(xs, 2, 0)); RH_NEED(s->pn, bx_slab(xs, 2, 0)); RH_NEED(s->pm, bx_slab(ys, 2, 0)); RH_NEED(s->pn, bx_slab(ys, 2, 0));
     RH_NEED(s->DU_avg1, bx_slab(xbx, 2, 0)); RH_NEED(s->DV_avg1, bx_slab(ybx, 2, 0)); RH_NEED(s->msku, bx_slab(xbx, 2, 0)); RH_NEED(s->mskv, bx_slab(ybx, 2, 0));
     const dim3 gx((xbx.hi[0] - xbx.lo[0] + 63) / 63, xbx.hi[1] - xbx.lo[1] + 1, 1), gy((ybx.hi[0] - ybx.lo[0] + 64) / 64, ybx.hi[1] - ybx.lo[1] + 1, 1);
+    const bool reg = vv_reg_depth(N + 1) && !c->noregsolve;
+    const size_t lds_reg = sizeof(double) * 2 * (size_t)(N + 1) * 64;
+#define RH_VVU(NZ) k_column_solver_reg<1, 0, 1, VV_D_U, NZ><<<gx, 64, lds_reg, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn), \
+        mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab)
+#define RH_VVV(NZ) k_column_solver_reg<0, 1, 1, VV_D_V, NZ><<<gy, 64, lds_reg, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm), \
+        mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab)
     { TScope t(c, "uv_corrector");
-    k_column_solver<1, 0, 1, VV_D_U><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn),
+    if (reg) { switch (N + 1) { case 13: RH_VVU(13); break; case 16: RH_VVU(16); break; default: RH_VVU(50); break; } }
+    else k_column_solver<1, 0, 1, VV_D_U><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn),
         mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab);
     RH_LAUNCH_CHECK(); }
     TScope t(c, "uv_corrector");
-    k_column_solver<0, 1, 1, VV_D_V><<<gy, 64, lds_bytes, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm),
+    if (reg) { switch (N + 1) { case 13: RH_VVV(13); break; case 16: RH_VVV(16); break; default: RH_VVV(50); break; } }
+    else k_column_solver<0, 1, 1, VV_D_V><<<gy, 64, lds_bytes, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm),
         mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab);
     RH_LAUNCH_CHECK();
     *applied = 1;

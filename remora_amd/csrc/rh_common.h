@@ -155,6 +155,7 @@ struct rh_ctx {
     std::vector<hipEvent_t> evpool;
     void *bcq = nullptr; int bc_defer = 0;                     // queued physical-BC passes (rh_halo.hip)
     void *haloq = nullptr;                                     // queued ghost exchanges of the same scope (rh_halo.hip)
+    bool noregsolve = false;         // RH_NOREGSOLVE=1: the LDS-ring column solver instead of the register form (A/B parity and timing)
     bool nofuse2d = false;           // RH_NOFUSE2D=1: advance_2d as three kernels + the DUon/DVom exchange instead of k2d_fused (A/B parity)
     bool unfused = false;            // RH_UNFUSED=1: drivers call the per-leaf entry points instead of the fused kernels (A/B parity)
     bool poison = false;             // RH_POISON=1: NaN-fill the work space at the start of every step (stale-read detector)

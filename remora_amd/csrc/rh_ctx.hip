@@ -291,6 +291,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     c->nfast = set_weights(prm->ndtfast, c->w1, c->w2);
     init_bcs(c);
     c->unfused = getenv("RH_UNFUSED") && atoi(getenv("RH_UNFUSED")) != 0;
+    c->noregsolve = getenv("RH_NOREGSOLVE") && atoi(getenv("RH_NOREGSOLVE")) != 0;
     c->nofuse2d = getenv("RH_NOFUSE2D") && atoi(getenv("RH_NOFUSE2D")) != 0;
     c->poison = getenv("RH_POISON") && atoi(getenv("RH_POISON")) != 0;
 
