@@ -106,8 +106,10 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
                 RH_TRY(rh_prestep_t(c, bx, a4_comp(s->cons_old, n), a4_comp(s->cons_new, n), a4_comp(s->sstore, n), s->Hz, s->Huon, s->Hvom, c->W,
                                     s->pm, s->pn, s->msku, s->mskv, iic, ntfirst, N, dt));
         const rh_box tbxp1 = bx_grow(bx, 1, 1, 0);
-        RH_TRY(rh_prestep_uv(c, tbxp1, 1, 0, s->xvel_new, s->xvel_old, s->ru, s->Hz, s->sustr, s->bustr, s->pm, s->pn, iic, ntfirst, nrhs, N, dt));
-        RH_TRY(rh_prestep_uv(c, tbxp1, 0, 1, s->yvel_new, s->yvel_old, s->rv, s->Hz, s->svstr, s->bvstr, s->pm, s->pn, iic, ntfirst, nrhs, N, dt));
+        // ru / rv(nrhs) on the valid faces are assigned by prsgrd below before anything reads them: prestep_uv skips that store there
+        const rh_box none = bx_make(0, 0, 0, -1, -1, -1);
+        RH_TRY(launch_prestep_uv(c, tbxp1, c->unfused ? none : bx_nodal(bx, 0), 1, 0, s->xvel_new, s->xvel_old, s->ru, s->Hz, s->sustr, s->bustr, s->pm, s->pn, iic, ntfirst, nrhs, N, dt));
+        RH_TRY(launch_prestep_uv(c, tbxp1, c->unfused ? none : bx_nodal(bx, 1), 0, 1, s->yvel_new, s->yvel_old, s->rv, s->Hz, s->svstr, s->bvstr, s->pm, s->pn, iic, ntfirst, nrhs, N, dt));
     }
     {
         TScope t(c, "halo");

@@ -328,9 +328,11 @@ extern "C" int rh_prestep_t(rh_ctx *c, rh_box tbx, rh_array4 told, rh_array4 tne
 // REMORA::prestep_diffusion for u (ioff = 1) or v (joff = 1), REMORA_prestep_diffusion.cpp:19-165 with lambda = 1
 // (REMORA_prestep.cpp:101): vel*Hz + surface/bottom stress + Adams-Bashforth weighting of the stored right-hand sides,
 // including the in-place component swap of rvel (:128-131,154-161).
-__global__ void k_prestep_uv(B3 bx, int ioff, int joff, A4 vel, A4 vel_old, A4 rvel, A4 Hz, A4 sstr, A4 bstr, A4 pm, A4 pn,
+__global__ void k_prestep_uv(B3 bx, B3 dead, int ioff, int joff, A4 vel, A4 vel_old, A4 rvel, A4 Hz, A4 sstr, A4 bstr, A4 pm, A4 pn,
                              int step, int nrhs, int N, double dt)
 {
+    // `dead`: points whose rvel(nrhs) is overwritten before anything reads it (setup_step: prsgrd assigns ru / rv(nrhs) on the valid
+    // faces right after prestep, REMORA_prsgrd.cpp:134-149,181-196); the store is skipped there.  Empty for the stand-alone leaf.
     // no level depends on another (lambda = 1 removes the vertical flux divergence): one thread per point, grid.z walks k
     RH_IJ(bx); if (!inb2(bx, i, j)) return;
     const int k = bx.lo2 + RH_KZ;
@@ -344,19 +346,35 @@ __global__ void k_prestep_uv(B3 bx, int ioff, int joff, A4 vel, A4 vel_old, A4 r
     const double DC = 0.25 * dt * (pm(i, j, 0) + pm(ii, jj, 0)) * (pn(i, j, 0) + pn(ii, jj, 0));
     const double r_indx = rvel(i, j, k, indx), r_nrhs = rvel(i, j, k, nrhs);
     rvel(i, j, k, indx) = r_nrhs;                                     // swap
+    const bool keep = !inb2(dead, i, j);
     if (step == 1) {
-        rvel(i, j, k, nrhs) = r_indx;
+        if (keep) rvel(i, j, k, nrhs) = r_indx;
         const double cff3 = 0.5 * DC;
         vel(i, j, k) = a - cff3 * r_nrhs + b;
     } else {
         const double cff1 = 5.0 / 12.0, cff2 = 16.0 / 12.0;
         vel(i, j, k) = a + DC * (cff1 * r_indx - cff2 * r_nrhs) + b;
-        rvel(i, j, k, nrhs) = 0.0;
+        if (keep) rvel(i, j, k, nrhs) = 0.0;
     }
 }
+static int prestep_uv(rh_ctx *c, rh_box vel_bx, rh_box dead, int ioff, int joff, rh_array4 vel, rh_array4 vel_old, rh_array4 rvel,
+                      rh_array4 Hz, rh_array4 sstr, rh_array4 bstr, rh_array4 pm, rh_array4 pn,
+                      int iic, int ntfirst, int nrhs, int N, double dt);
 extern "C" int rh_prestep_uv(rh_ctx *c, rh_box vel_bx, int ioff, int joff, rh_array4 vel, rh_array4 vel_old, rh_array4 rvel,
                              rh_array4 Hz, rh_array4 sstr, rh_array4 bstr, rh_array4 pm, rh_array4 pn,
                              int iic, int ntfirst, int nrhs, int N, double dt)
+{
+    return prestep_uv(c, vel_bx, bx_make(0, 0, 0, -1, -1, -1), ioff, joff, vel, vel_old, rvel, Hz, sstr, bstr, pm, pn, iic, ntfirst, nrhs, N, dt);
+}
+// the call of setup_step: `dead` = the faces on which prsgrd assigns rvel(nrhs) next
+int launch_prestep_uv(rh_ctx *c, rh_box vel_bx, rh_box dead, int ioff, int joff, rh_array4 vel, rh_array4 vel_old, rh_array4 rvel,
+                      rh_array4 Hz, rh_array4 sstr, rh_array4 bstr, rh_array4 pm, rh_array4 pn, int iic, int ntfirst, int nrhs, int N, double dt)
+{
+    return prestep_uv(c, vel_bx, dead, ioff, joff, vel, vel_old, rvel, Hz, sstr, bstr, pm, pn, iic, ntfirst, nrhs, N, dt);
+}
+static int prestep_uv(rh_ctx *c, rh_box vel_bx, rh_box dead, int ioff, int joff, rh_array4 vel, rh_array4 vel_old, rh_array4 rvel,
+                      rh_array4 Hz, rh_array4 sstr, rh_array4 bstr, rh_array4 pm, rh_array4 pn,
+                      int iic, int ntfirst, int nrhs, int N, double dt)
 {
     TScope t(c, "prestep_uv");
     if ((ioff | joff) != 1 || (ioff & joff)) return rh_fail("rh_prestep_uv: (ioff,joff) must be (1,0) or (0,1)");
@@ -367,7 +385,7 @@ extern "C" int rh_prestep_uv(rh_ctx *c, rh_box vel_bx, int ioff, int joff, rh_ar
     RH_NEED(vel, vel_bx); RH_NEED(vel_old, vel_bx); RH_NEED(rvel, vel_bx); RH_NEED(Hz, bs);
     RH_NEED(sstr, b2); RH_NEED(bstr, b2); RH_NEED(pm, bs2); RH_NEED(pn, bs2);
     const int step = (iic == ntfirst) ? 0 : (iic == ntfirst + 1 ? 1 : 2);
-    k_prestep_uv<<<grid3(vel_bx), rh_block(), 0, c->stream>>>(mkB(vel_bx), ioff, joff, mkA(vel), mkA(vel_old), mkA(rvel), mkA(Hz),
+    k_prestep_uv<<<grid3(vel_bx), rh_block(), 0, c->stream>>>(mkB(vel_bx), mkB(dead), ioff, joff, mkA(vel), mkA(vel_old), mkA(rvel), mkA(Hz),
         mkA(sstr), mkA(bstr), mkA(pm), mkA(pn), step, nrhs, N, dt);
     RH_LAUNCH_CHECK(); return 0;
 }
