@@ -32,8 +32,8 @@ ALGO_DOUBLES = {
     "uv_corrector": 4 + 1,         # u, ru, Hz, Akv -> u     (AB3 + vert_visc_3d + vert_mean_3d; one launch per velocity)
     "vert_visc_3d": 3 + 1,         # phi, Hz, Akt -> phi
     "update_massflux_3d": 3 + 1,   # phi, Hphi, Hz -> Hphi (+ phi on boundary faces only)
-    "prsgrd": 4 + 2,               # rho, z_r, Hz, (z_w top level) -> ru, rv   (P is scratch: not counted)
-    "rho_eos": 4 + 2,              # T, S, Hz, z_r -> rho, bvf
+    "prsgrd": 4 + 2,               # rho, P, z_r, Hz -> ru, rv
+    "rho_eos": 4 + 3,              # T, S, Hz, z_r -> rho, bvf, P   (the hydrostatic pressure of prsgrd rides on the same sweep)
     "omega": 3 + 1,                # Huon, Hvom, z_w -> W
     "prestep_uv": 4 + 3,           # vel_old, Hz, rvel x2 -> vel, rvel x2
     "stretch_transform": 0 + 3,
@@ -44,7 +44,7 @@ ALGO_DOUBLES = {
 GROUP_KERNELS = {
     "prestep_t3": ["k_tracers_tiled<0"], "rhs_t3": ["k_tracers_tiled<1"], "rhs_uv_3d": ["k_rhs_uv_tiled"], "uv3dmix": ["k_uv3dmix_tiled"],
     "uv_corrector": ["k_column_solver_reg<1, 0, 1", "k_column_solver_reg<0, 1, 1"], "vert_visc_3d": ["k_column_solver_reg<0, 0, 0"],
-    "update_massflux_3d": ["k_massflux_lds"], "prsgrd": ["k_prsgrd_P", "k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos"], "omega": ["k_omega_lds"],
+    "update_massflux_3d": ["k_massflux_lds"], "prsgrd": ["k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos_P"], "omega": ["k_omega_lds"],
     "prestep_uv": ["k_prestep_uv"], "stretch_transform": ["k_stretch"], "vmix": ["k_vmix"], "massflux_old": ["k_massflux_old"],
 }
 

@@ -155,6 +155,7 @@ struct rh_ctx {
     std::vector<hipEvent_t> evpool;
     void *bcq = nullptr; int bc_defer = 0;                     // queued physical-BC passes (rh_halo.hip)
     void *haloq = nullptr;                                     // queued ghost exchanges of the same scope (rh_halo.hip)
+    bool P_ready = false;            // prsgrd's hydrostatic pressure was already formed by launch_rho_eos_P (rh_setup.hip)
     bool noregsolve = false;         // RH_NOREGSOLVE=1: the LDS-ring column solver instead of the register form (A/B parity and timing)
     bool nofuse2d = false;           // RH_NOFUSE2D=1: advance_2d as three kernels + the DUon/DVom exchange instead of k2d_fused (A/B parity)
     bool unfused = false;            // RH_UNFUSED=1: drivers call the per-leaf entry points instead of the fused kernels (A/B parity)
@@ -190,6 +191,7 @@ int  launch_set_zeta(rh_ctx *c, rh_state *s);
 int  launch_uv_ab3(rh_ctx *c, rh_state *s, int istep);
 int  launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied);   // fused: AB3 + vert_visc_3d + vert_mean_3d for u, v
 int  launch_mask_cons(rh_ctx *c, rh_state *s);
+int  launch_rho_eos_P(rh_ctx *c, rh_state *s, rh_box bx, rh_box pbx);
 int  launch_prestep_uv(rh_ctx *c, rh_box vel_bx, rh_box dead, int ioff, int joff, rh_array4 vel, rh_array4 vel_old, rh_array4 rvel,
                        rh_array4 Hz, rh_array4 sstr, rh_array4 bstr, rh_array4 pm, rh_array4 pn, int iic, int ntfirst, int nrhs, int N, double dt);
 int  launch_prestep_t3(rh_ctx *c, rh_state *s, int iic, int ntfirst);   // fused: 3 tracers x (prestep_t + t3dmix)

@@ -63,6 +63,7 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     const int N = c->N, iic = istep, ntfirst = 0, nrhs = 0;
     const double dt = P.dt;
     const rh_box bx = c->bx;
+    c->P_ready = false;
     if (c->poison) { RH_HIP(hipMemsetAsync(c->d_work, 0xFF, c->work_bytes, c->stream)); }
     {
         TScope t(c, "halo");
@@ -91,7 +92,8 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
         RH_TRY(bcs.end());
     }
     { TScope t(c, "massflux_old"); RH_TRY(launch_massflux_old(c, s)); }                            // :187-197
-    RH_TRY(rh_rho_eos(c, bx_grow(bx, 2, 2, 0), s->cons_old, c->rho, s->rhoA, s->rhoS, s->bvf, s->Hz, s->z_w, s->z_r, s->h, s->mskr, N));   // :200
+    if (c->unfused) RH_TRY(rh_rho_eos(c, bx_grow(bx, 2, 2, 0), s->cons_old, c->rho, s->rhoA, s->rhoS, s->bvf, s->Hz, s->z_w, s->z_r, s->h, s->mskr, N));   // :200
+    else RH_TRY(launch_rho_eos_P(c, s, bx_grow(bx, 2, 2, 0), bx_grow(bx, 1, 1, 0)));     // + the hydrostatic pressure of prsgrd (:229-260), same operands
     RH_TRY(set_analytical_vmix(c, s));                                                             // :203-206
     RH_TRY(launch_set_zeta(c, s));                                                                 // :208
     // :210-211 mf_W.setVal(0): omega overwrites every level of the grow-1 box, so only the frame around it needs the zero

@@ -476,6 +476,94 @@ __global__ void k_prsgrd_uv(B3 ub, B3 vb, B3 un, A4 ru, A4 rv, A4 pn, A4 pm, A4 
 // LDS-tiled form: the direct form asks the fabric for 13 doubles per cell where 4 are distinct (profiles/r1_v3_traffic.json).  A
 // block walks the column of one 64 x 8 tile: per level it stages rho, z_r (halo 2) and P, Hz (halo 1) in LDS (double-buffered on
 // the parity of k, the next level's values already on their way), and every stencil neighbour is read from LDS.
+// rho_eos and the hydrostatic pressure of prsgrd in ONE downward sweep (setup_step calls them back to back on unchanged operands:
+// REMORA_setup_step.cpp:200 and :229-260).  rho(k) is formed from T, S as in k_rho_eos and P(k+1) follows one level behind with the
+// three densities it needs still in registers, so prsgrd never re-reads rho and z_r.  Same expressions, same order: bit-identical
+// to k_rho_eos followed by k_prsgrd_P.  P is written on pbx (the grow-1 box) only.
+__global__ void k_rho_eos_P(B3 bx, B3 pbx, A4 st, A4 rho, A4 rhoA, A4 rhoS, A4 bvf, A4 Hz, A4 z_w, A4 z_r, A4 h, A4 mskr, A4 P, int N,
+                            double R0, double S0, double T0, double Tcoef, double Scoef, double rho0, double g)
+{
+    RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    const bool doP = inb2(pbx, i, j);
+    const double m = mskr(i, j, 0);
+    const double gorho0 = g / rho0;
+    const double GRho = g / rho0, GRho0 = 1000.0 * GRho, HalfGRho = 0.5 * GRho;
+    const double OneFifth = 0.2, OneTwelfth = 1.0 / 12.0;
+    const double zwtop = z_w(i, j, N + 1);
+    double r_up = 0.0, z_up = 0.0, A = 0.0, S = 0.0;
+    double dRraw_k = 0, dZraw_k = 0, dRh_k1 = 0, dZh_k1 = 0, r_k1 = 0, z_k1 = 0, r_k = 0, z_k = 0, Pk1 = 0;
+    for (int k = N; k >= 0; k--) {
+        const double r = (R0 - R0 * Tcoef * (st(i, j, k, 0) - T0) + R0 * Scoef * (st(i, j, k, 1) - S0) - 1000.0) * m;
+        rho(i, j, k) = r;
+        const double hz = Hz(i, j, k), zr = z_r(i, j, k);
+        if (k == N) { const double cff0 = r * hz; S = 0.5 * cff0 * hz; A = cff0; }
+        else {
+            const double cff1 = r * hz; S += hz * (A + 0.5 * cff1); A += cff1;
+            bvf(i, j, k + 1) = -gorho0 * (r_up - r) / (z_up - zr);
+        }
+        if (doP) {
+            if (k == N - 1) {                              // P(N) and the slopes at level N, prsgrd.cpp:54-79
+                const double rN = r_up, rN1 = r, zN = z_up, zN1 = zr;
+                const double cff1 = 1.0 / (zN - zN1);
+                const double cff2 = 0.5 * (rN - rN1) * (zwtop - zN) * cff1;
+                Pk1 = GRho0 * zwtop + GRho * (rN + cff2) * (zwtop - zN);
+                P(i, j, N) = Pk1;
+                const double dRraw_k1 = rN - rN1, dZraw_k1 = zN - zN1;
+                dRraw_k = rN - rN1; dZraw_k = zN - zN1;
+                dRh_k1 = hmean_eps(dRraw_k1, dRraw_k);
+                dZh_k1 = 2.0 * dZraw_k1 * dZraw_k / (dZraw_k1 + dZraw_k);
+                r_k1 = rN; z_k1 = zN; r_k = rN1; z_k = zN1;
+            } else if (k <= N - 2) {                       // P(k+1): r, zr are level k = (k+1) - 1
+                const double r_km = r, z_km = zr;
+                const double dRraw_km = r_k - r_km, dZraw_km = z_k - z_km;
+                const double dRh_k = hmean_eps(dRraw_k, dRraw_km);
+                const double dZh_k = 2.0 * dZraw_k * dZraw_km / (dZraw_k + dZraw_km);
+                const double rho_diff = r_k1 - r_k - OneTwelfth * (dRh_k1 + dRh_k);
+                const double z_diff = z_k1 - z_k - OneTwelfth * (dZh_k1 + dZh_k);
+                const double rz_avg = (r_k1 + r_k) * (z_k1 - z_k);
+                const double Pk = Pk1 + HalfGRho * (rz_avg - OneFifth * ((dRh_k1 - dRh_k) * z_diff - (dZh_k1 - dZh_k) * rho_diff));
+                P(i, j, k + 1) = Pk;
+                Pk1 = Pk; dRh_k1 = dRh_k; dZh_k1 = dZh_k; r_k1 = r_k; z_k1 = z_k; r_k = r_km; z_k = z_km;
+                dRraw_k = dRraw_km; dZraw_k = dZraw_km;
+            }
+        }
+        r_up = r; z_up = zr;
+    }
+    if (doP) {                                             // P(0): the slope below level 0 repeats d(0)
+        const double dRraw_km = dRraw_k, dZraw_km = dZraw_k;
+        const double dRh_k = hmean_eps(dRraw_k, dRraw_km);
+        const double dZh_k = 2.0 * dZraw_k * dZraw_km / (dZraw_k + dZraw_km);
+        const double rho_diff = r_k1 - r_k - OneTwelfth * (dRh_k1 + dRh_k);
+        const double z_diff = z_k1 - z_k - OneTwelfth * (dZh_k1 + dZh_k);
+        const double rz_avg = (r_k1 + r_k) * (z_k1 - z_k);
+        P(i, j, 0) = Pk1 + HalfGRho * (rz_avg - OneFifth * ((dRh_k1 - dRh_k) * z_diff - (dZh_k1 - dZh_k) * rho_diff));
+    }
+    const double cff2 = 1.0 / rho0;
+    const double cff11 = 1.0 / (zwtop + h(i, j, 0, 0));
+    A *= cff2 * cff11;
+    S *= 2.0 * cff11 * cff11 * cff2;
+    rhoA(i, j, 0) = A; rhoS(i, j, 0) = S;
+}
+// setup_step's form of rho_eos: also leaves prsgrd's P behind (c->P_ready tells the following rh_prsgrd to skip its first kernel)
+int launch_rho_eos_P(rh_ctx *c, rh_state *s, rh_box bx, rh_box pbx)
+{
+    TScope t(c, "rho_eos");
+    const int N = c->N;
+    const rh_box b2 = bx_slab(bx, 2, 0);
+    rh_box bw = bx; bw.lo[2] = 0; bw.hi[2] = N + 1;
+    bx.lo[2] = 0; bx.hi[2] = N; pbx.lo[2] = 0; pbx.hi[2] = N;
+    if (s->cons_old.ncomp < 2) return rh_fail("rho_eos: state needs temp and salt");
+    if (!bx_contains(bx, pbx)) return rh_fail("rho_eos: pressure box outside the density box");
+    RH_NEED(s->cons_old, bx); RH_NEED(c->rho, bx); RH_NEED(s->Hz, bx); RH_NEED(s->z_r, bx); RH_NEED(s->z_w, bw); RH_NEED(s->bvf, bw);
+    RH_NEED(s->rhoA, b2); RH_NEED(s->rhoS, b2); RH_NEED(s->h, b2); RH_NEED(s->mskr, b2); RH_NEED(c->P, pbx);
+    const rh_params &P = c->prm;
+    k_rho_eos_P<<<grid2(bx), rh_block(), 0, c->stream>>>(mkB(bx), mkB(pbx), mkA(s->cons_old), mkA(c->rho), mkA(s->rhoA), mkA(s->rhoS), mkA(s->bvf), mkA(s->Hz),
+        mkA(s->z_w), mkA(s->z_r), mkA(s->h), mkA(s->mskr), mkA(c->P), N, P.R0, P.S0, P.T0, P.Tcoef, P.Scoef, P.rho0, P.g);
+    RH_LAUNCH_CHECK();
+    c->P_ready = true;
+    return 0;
+}
+
 __global__ void __launch_bounds__(RT_BX * RT_BY)
 k_prsgrd_uv_tiled(B3 ub, B3 vb, B3 un, A4 ru, A4 rv, A4 pn, A4 pm, A4 rho, A4 P, A4 Hz, A4 z_r, A4 msku, A4 mskv, int nrhs, double HalfGRho)
 {
@@ -520,6 +608,8 @@ extern "C" int rh_prsgrd(rh_ctx *c, rh_box phi_bx, rh_box utbx, rh_box vtbx, rh_
     RH_NEED(P, phi_bx); RH_NEED(rho, phi_bx); RH_NEED(z_r, phi_bx); RH_NEED(z_w, bw);
     const rh_params &Pm = c->prm;
     const double GRho = Pm.g / Pm.rho0, GRho0 = 1000.0 * GRho, HalfGRho = 0.5 * GRho;
+    if (c->P_ready && P.p == c->P.p) c->P_ready = false;          // left behind by launch_rho_eos_P on this very box
+    else
     k_prsgrd_P<<<grid2(phi_bx), rh_block(), 0, c->stream>>>(mkB(phi_bx), mkA(P), mkA(rho), mkA(z_r), mkA(z_w), N, GRho, GRho0, HalfGRho);
     RH_LAUNCH_CHECK();
     rh_box us = utbx; us.lo[0] -= 2; us.hi[0] += 1; rh_box vs = vtbx; vs.lo[1] -= 2; vs.hi[1] += 1;
