@@ -163,3 +163,18 @@ def test_reductions_against_oracle(case):
     else:
         assert abs(a[3] - b[3]) <= 1e-12 * abs(b[3])
     rem.close(); orc.close()
+
+
+@pytest.mark.parametrize("nz", [50, 64, 20])
+def test_deep_columns_against_oracle(nz):
+    """The column kernels pick their form by depth: register-resident solver for the depths it is built for (13, 16, 50), LDS ring
+    kernel otherwise, with the dynamic-LDS opt-in above 62 levels (nz = 64 is the depth of BASELINE configs[4]).  Seamount physics
+    (steep bathymetry, no device transcendental: bit-exact) on its own horizontal grid with nz levels, three steps, all fields."""
+    cfg = cases.get("Seamount")
+    cfg["ncell"] = (cfg["ncell"][0], cfg["ncell"][1], nz)
+    orc = Oracle(cfg); rem = REMORA(cfg)
+    upload_oracle_state(orc, rem)
+    for step in range(3):
+        orc.advance(1); rem.timeStep()
+        _check(compare_states(orc, rem), "Seamount", f"nz {nz} step {step}")
+    rem.close(); orc.close()
