@@ -155,6 +155,10 @@ int  rh_prestep_uv(rh_ctx *ctx, rh_box vel_bx, int ioff, int joff, rh_array4 vel
 /* REMORA::t3dmix, TimeIntegration/REMORA_t3dmix.cpp:6-58 */
 int  rh_t3dmix(rh_ctx *ctx, rh_box bx, rh_array4 state, rh_array4 state_rhs, rh_array4 diff2, rh_array4 Hz, rh_array4 pm,
                rh_array4 pn, rh_array4 msku, rh_array4 mskv, double dt, int ncomp);
+/* REMORA::coriolis, TimeIntegration/REMORA_coriolis.cpp:10-40, as a leaf of its own (fomn = fcor / (pm pn), REMORA_setup_step.cpp:233-239;
+ * also the 2-D call of REMORA_advance_2d.cpp:530 with Hz := Drhs on k = 0 slabs).  Inside rh_rhs_uv_3d / rh_advance_2d it is fused. */
+int  rh_coriolis(rh_ctx *ctx, rh_box xbx, rh_box ybx, rh_array4 uold, rh_array4 vold, rh_array4 ru, rh_array4 rv,
+                 rh_array4 Hz, rh_array4 fomn, int nrhs, int nr);
 /* REMORA::coriolis + REMORA::rhs_uv_3d, TimeIntegration/REMORA_coriolis.cpp:10-40, REMORA_rhs_uv_3d.cpp:31-385 */
 int  rh_rhs_uv_3d(rh_ctx *ctx, rh_box xbx, rh_box ybx, rh_array4 uold, rh_array4 vold, rh_array4 ru, rh_array4 rv,
                   rh_array4 rufrc, rh_array4 rvfrc, rh_array4 sustr, rh_array4 svstr, rh_array4 bustr, rh_array4 bvstr,

@@ -827,6 +827,37 @@ __global__ void k_rhs_uv_3d(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv,
         rvfrc(i, j, 0) = frc;
     }
 }
+// REMORA::coriolis as a leaf of its own, REMORA_coriolis.cpp:10-40 (inside the drivers it is folded into the momentum kernels).
+// Also serves the 2-D call of advance_2d.cpp:530 (Hz := Drhs, k = 0 slabs).
+__global__ void k_coriolis(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 Hz, A4 fomn, int nrhs, int nr)
+{
+    RH_IJ(un);
+    const int k = un.lo2 + RH_KZ;
+    if (inb2(xb, i, j)) {
+        const double UFx_i = 0.5 * Hz(i, j, k) * fomn(i, j, 0) * (vold(i, j, k, nrhs) + vold(i, j + 1, k, nrhs));
+        const double UFx_im1 = 0.5 * Hz(i - 1, j, k) * fomn(i - 1, j, 0) * (vold(i - 1, j, k, nrhs) + vold(i - 1, j + 1, k, nrhs));
+        ru(i, j, k, nr) += 0.5 * (UFx_i + UFx_im1);
+    }
+    if (inb2(yb, i, j)) {
+        const double VFe_j = 0.5 * Hz(i, j, k) * fomn(i, j, 0) * (uold(i, j, k, nrhs) + uold(i + 1, j, k, nrhs));
+        const double VFe_jm1 = 0.5 * Hz(i, j - 1, k) * fomn(i, j - 1, 0) * (uold(i, j - 1, k, nrhs) + uold(i + 1, j - 1, k, nrhs));
+        rv(i, j, k, nr) -= 0.5 * (VFe_j + VFe_jm1);
+    }
+}
+extern "C" int rh_coriolis(rh_ctx *c, rh_box xbx, rh_box ybx, rh_array4 uold, rh_array4 vold, rh_array4 ru, rh_array4 rv,
+                           rh_array4 Hz, rh_array4 fomn, int nrhs, int nr)
+{
+    TScope t(c, "coriolis");
+    if (xbx.lo[2] != ybx.lo[2] || xbx.hi[2] != ybx.hi[2]) return rh_fail("rh_coriolis: xbx and ybx must span the same levels");
+    if (nrhs < 0 || nrhs >= uold.ncomp || nrhs >= vold.ncomp || nr < 0 || nr >= ru.ncomp || nr >= rv.ncomp) return rh_fail("rh_coriolis: component out of range");
+    { rh_box q = xbx; q.lo[0] -= 1; q.hi[1] += 1; RH_NEED(vold, q); RH_NEED(Hz, bx_growlo_i(xbx)); RH_NEED(fomn, bx_slab(bx_growlo_i(xbx), 2, 0)); }
+    { rh_box q = ybx; q.lo[1] -= 1; q.hi[0] += 1; RH_NEED(uold, q); RH_NEED(Hz, bx_growlo_j(ybx)); RH_NEED(fomn, bx_slab(bx_growlo_j(ybx), 2, 0)); }
+    RH_NEED(ru, xbx); RH_NEED(rv, ybx);
+    const rh_box un = bx_union(xbx, ybx);
+    k_coriolis<<<grid3(un), rh_block(), 0, c->stream>>>(mkB(xbx), mkB(ybx), mkB(un), mkA(uold), mkA(vold), mkA(ru), mkA(rv), mkA(Hz), mkA(fomn), nrhs, nr);
+    RH_LAUNCH_CHECK(); return 0;
+}
+
 // ---- LDS-tiled, software-pipelined form of k_rhs_uv_3d (same arithmetic).  uold, vold, Huon, Hvom, W(k+1) are staged with a
 // halo of 2 and Hz with a halo of 1; each thread loads its own point of every field once per level, one level ahead of its use;
 // the vertical flux uses a 4-level register window.  k-invariant per-thread values (Coriolis factors, stress terms) sit in LDS.

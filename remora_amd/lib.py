@@ -116,6 +116,7 @@ SIGNATURES = {
     "rh_prestep_t": (C.c_int, [_P, Box] + [_A] * 11 + [C.c_int, C.c_int, C.c_int, C.c_double]),
     "rh_prestep_uv": (C.c_int, [_P, Box, C.c_int, C.c_int] + [_A] * 8 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
     "rh_t3dmix": (C.c_int, [_P, Box] + [_A] * 8 + [C.c_double, C.c_int]),
+    "rh_coriolis": (C.c_int, [_P, Box, Box] + [_A] * 6 + [C.c_int, C.c_int]),
     "rh_rhs_uv_3d": (C.c_int, [_P, Box, Box] + [_A] * 17 + [C.c_int, C.c_int, C.c_int]),
     "rh_uv3dmix": (C.c_int, [_P, Box, Box] + [_A] * 12 + [C.c_int, C.c_int, C.c_double]),
     "rh_vert_visc_3d": (C.c_int, [_P, Box, C.c_int, C.c_int, _A, _A, _A, C.c_int, C.c_double]),
