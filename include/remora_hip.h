@@ -212,10 +212,11 @@ int  rh_est_timestep(rh_ctx *ctx, rh_state *s, double cfl, int local_only, doubl
 int  rh_sum_integrated_quantities(rh_ctx *ctx, rh_state *s, int local_only, double out4[4]);
 
 /* ---- synthetic initial state (outside the hot path; what InitData / prob.cpp provide in REMORA) ---- */
-/* Fills a bound native state for one of the pinned problems (0 Upwelling, 1 Seamount, 2 DoubleGyre, 3 Advection):
+/* Fills a bound native state for one of the pinned problems (0 Upwelling, 1 Seamount, 2 DoubleGyre, 3 Advection, 4 DoublyPeriodic):
  * Source/REMORA.cpp:246-342,608-702, Initialization/REMORA_init.cpp, Exec/<case>/prob.cpp.  Synchronises. */
 typedef struct rh_init_params {
     int prob; double rdrag, coriolis_f0, coriolis_beta; int hmix_constant; double visc2, tnu2[RH_NCONS]; double u_0, v_0;
+    double z0, zRef, uRef;       /* prob.z0 / prob.zRef / prob.uRef of Exec/DoublyPeriodic (log-layer x-velocity) */
 } rh_init_params;
 int  rh_init_state(rh_ctx *ctx, rh_state *s, const rh_init_params *ip);
 /* plotfile variables of IO/REMORA_Plotfile.cpp:185-235 on the valid box: temp, salt, [scalar], cell-centred u, v, w

@@ -107,6 +107,26 @@ static void init_bathymetry(OState *s)
         } else FORBOX2D(g3,i,j){ VN(h,i,j,0,0)=-P->prob_lo[2]; VN(h,i,j,0,1)=VN(h,i,j,0,0); }
     } break;
     case CASE_DOUBLEGYRE: fab_setval(h,500.0); break;                          /* Exec/DoubleGyre/prob.cpp:21-28 */
+    case CASE_DOUBLYPERIODIC: {                                                /* Exec/DoublyPeriodic/prob.cpp:32-105 */
+        fab_setval(h,P->prob_hi[2]);
+        int Lm=s->nx, Mm=s->ny;
+        Box g2=box_slab(box_grow(s->bx,NGROW,NGROW,0),2,0);
+        if(!P->flat_bathymetry){
+            if(P->periodic[1]){
+                FORBOX2D(g2,i,j){
+                    int iFort=i+1;
+                    double val1=(iFort<=Lm/2.0)?iFort:Lm+1-iFort;
+                    VN(h,i,j,0,0)=dmin(-P->prob_lo[2],(84.5+66.526*tanh((val1-10.0)/7.0)));
+                }
+            } else if(P->periodic[0]){
+                FORBOX2D(g2,i,j){
+                    int jFort=j+1;
+                    double val1=(jFort<=Mm/2.0)?jFort:Mm+1-jFort;
+                    VN(h,i,j,0,0)=dmin(-P->prob_lo[2],(84.5+66.526*tanh((val1-10.0)/7.0)));
+                }
+            }
+        } else FORBOX2D(g2,i,j){ VN(h,i,j,0,0)=-P->prob_lo[2]; VN(h,i,j,0,1)=VN(h,i,j,0,0); }
+    } break;
     case CASE_ADVECTION: {                                                     /* Exec/Advection/prob.cpp:29-52 */
         fab_setval(h,P->prob_hi[2]);
         Box b=fab_box(h);
@@ -142,6 +162,17 @@ static void init_prob(OState *s)
             VN(st,i,j,k,2)=0.0;
         }
     } break;
+    case CASE_DOUBLYPERIODIC:                                                  /* Exec/DoublyPeriodic/prob.cpp:126-180 */
+        FORBOX(s->bx,i,j,k){
+            double z=V(z_r,i,j,k);
+            VN(st,i,j,k,0)=T0+8.0*exp(z/50.0);
+            if(P->use_salt) VN(st,i,j,k,1)=S0;
+            double xcent=0.5*(P->prob_lo[0]+P->prob_hi[0]), ycent=0.5*(P->prob_lo[1]+P->prob_hi[1]);
+            double x=P->prob_lo[0]+(i+0.5)*dx0-xcent, y=P->prob_lo[1]+(j+0.5)*dx1-ycent;
+            double r2=x*x+y*y, rad=0.1*(P->prob_hi[0]-P->prob_lo[0]), radsq=rad*rad;
+            VN(st,i,j,k,2)=(r2<radsq)?1.0:0.0;
+        }
+        break;
     case CASE_ADVECTION:                                                       /* Exec/Advection/prob.cpp:72-157 */
         FORBOX(s->bx,i,j,k){
             VN(st,i,j,k,0)=T0;
@@ -153,7 +184,12 @@ static void init_prob(OState *s)
         }
         break;
     }
-    double u0=(P->prob==CASE_ADVECTION)?P->u_0:0.0, v0=(P->prob==CASE_ADVECTION)?P->v_0:0.0;
+    double u0=(P->prob==CASE_ADVECTION)?P->u_0:0.0, v0=(P->prob==CASE_ADVECTION||P->prob==CASE_DOUBLYPERIODIC)?P->v_0:0.0;
+    if(P->prob==CASE_DOUBLYPERIODIC){                                          /* Exec/DoublyPeriodic/prob.cpp:182-198: log layer */
+        Box b=s->xvel_new.valid; Fab f=F(xvel_new);
+        FORBOX(b,i,j,k){ double z=-V(z_r,i,j,k);
+            V(f,i,j,k)=P->u_0+P->uRef*log((z+P->z0)/P->z0)/log((P->zRef+P->z0)/P->z0); }
+    } else
     { Box b=s->xvel_new.valid; Fab f=F(xvel_new); FORBOX(b,i,j,k) V(f,i,j,k)=u0; }
     { Box b=s->yvel_new.valid; Fab f=F(yvel_new); FORBOX(b,i,j,k) V(f,i,j,k)=v0; }
     { Box b=s->zvel_new.valid; Fab f=F(zvel_new); FORBOX(b,i,j,k) V(f,i,j,k)=0.0; }
@@ -165,7 +201,7 @@ static void init_vmix(OState *s)
     Box b=box_grow(s->Akv.valid,NGROW,NGROW,0);
     FORBOX(b,i,j,k){
         switch(P->prob){
-        case CASE_UPWELLING: case CASE_ADVECTION:                              /* Exec/Upwelling/prob.cpp:163-185 */
+        case CASE_UPWELLING: case CASE_ADVECTION: case CASE_DOUBLYPERIODIC:    /* Exec/Upwelling/prob.cpp:163-185, DoublyPeriodic/prob.cpp:222-244 */
             V(Akv,i,j,k)=2.0e-03+8.0e-03*exp(V(z_w,i,j,k)/150.0);
             VN(Akt,i,j,k,0)=1.0e-6; VN(Akt,i,j,k,1)=1.0e-6; VN(Akt,i,j,k,2)=0.0; break;
         case CASE_SEAMOUNT:                                                    /* Exec/Seamount/prob.cpp:167-190 */
@@ -193,7 +229,7 @@ static void init_hmix(OState *s)
     } else {
         Box b=box_grow(s->bx,NGROW,NGROW,0);
         double v=0.0,d=0.0;
-        switch(P->prob){ case CASE_UPWELLING: case CASE_ADVECTION: v=5.0; d=0.0; break;
+        switch(P->prob){ case CASE_UPWELLING: case CASE_ADVECTION: case CASE_DOUBLYPERIODIC: v=5.0; d=0.0; break;
                          case CASE_SEAMOUNT: v=0.0; d=0.0; break; case CASE_DOUBLEGYRE: v=1280.0; d=1280.0; break; }
         FORBOX(b,i,j,k){ V(vp,i,j,k)=v; V(vr,i,j,k)=v; for(int n=0;n<NCONS;n++) VN(d2,i,j,k,n)=d; }
     }
@@ -206,7 +242,7 @@ static void init_smflux(OState *s,double time)
 {
     const Params *P=&s->prm; Fab su=F(sustr), sv=F(svstr);
     switch(P->prob){
-    case CASE_UPWELLING: {                                                     /* Exec/Upwelling/prob.cpp:214-255 */
+    case CASE_UPWELLING: case CASE_DOUBLYPERIODIC: {                           /* Exec/Upwelling/prob.cpp:214-255 == DoublyPeriodic/prob.cpp:274-308 */
         double pi=3.14159265359, tdays=time/(24.0*60.0*60.0), dstart=0.0, windamp=0.0;
         if(P->periodic[1]) fab_setval(su,0.0);
         else if(P->periodic[0]){

@@ -24,7 +24,7 @@ enum { BCV_CONS=0, BCV_TEMP=0, BCV_SALT, BCV_SCALAR, BCV_XVEL=NCONS, BCV_YVEL, B
 
 typedef struct { int lo[3], hi[3]; } BCRec;
 
-enum { CASE_UPWELLING=0, CASE_SEAMOUNT=1, CASE_DOUBLEGYRE=2, CASE_ADVECTION=3 };
+enum { CASE_UPWELLING=0, CASE_SEAMOUNT=1, CASE_DOUBLEGYRE=2, CASE_ADVECTION=3, CASE_DOUBLYPERIODIC=4 };
 
 typedef struct {
     /* geometry */
@@ -43,7 +43,8 @@ typedef struct {
     double visc2, tnu2[NCONS];
     /* problem */
     int    prob;                 /* CASE_* */
-    double u_0, v_0;             /* Advection prob.u_0 / prob.v_0 */
+    double u_0, v_0;             /* Advection / DoublyPeriodic prob.u_0 / prob.v_0 */
+    double z0, zRef, uRef;       /* DoublyPeriodic prob.z0 / prob.zRef / prob.uRef (log-layer x-velocity) */
     int    threads;              /* OpenMP threads for the timing baseline (0/1 = serial) */
 } Params;
 

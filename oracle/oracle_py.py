@@ -20,7 +20,8 @@ class Params(C.Structure):
                 ("Tcoef", C.c_double), ("Scoef", C.c_double), ("theta_s", C.c_double), ("theta_b", C.c_double),
                 ("tcline", C.c_double), ("rdrag", C.c_double), ("coriolis_f0", C.c_double), ("coriolis_beta", C.c_double),
                 ("hmix_constant", C.c_int), ("visc2", C.c_double), ("tnu2", C.c_double * 3), ("prob", C.c_int),
-                ("u_0", C.c_double), ("v_0", C.c_double), ("threads", C.c_int)]
+                ("u_0", C.c_double), ("v_0", C.c_double), ("z0", C.c_double), ("zRef", C.c_double), ("uRef", C.c_double),
+                ("threads", C.c_int)]
 
 
 def build(force=False):

@@ -6,13 +6,13 @@ the SolverChoice defaults of Source/REMORA_DataStruct.H:351-483 it leaves untouc
 """
 import copy
 
-PROB = {"Upwelling": 0, "Seamount": 1, "DoubleGyre": 2, "Advection": 3}
+PROB = {"Upwelling": 0, "Seamount": 1, "DoubleGyre": 2, "Advection": 3, "DoublyPeriodic": 4}
 
 _DEFAULTS = dict(
     flat_bathymetry=1, tracer_c4=0, uv_c2=0, use_coriolis=0, use_prestep=1, use_uv3dmix=1,
     use_barotropic=1, use_salt=1, g=9.81, rho0=1025.0, R0=1028.0, T0=5.0, S0=35.0, Tcoef=1.7e-4,
     Scoef=0.0, theta_s=3.0, theta_b=0.0, tcline=150.0, rdrag=3e-4, coriolis_f0=0.0, coriolis_beta=0.0,
-    hmix_constant=0, visc2=0.0, tnu2=(0.0, 0.0, 0.0), u_0=0.0, v_0=0.0,
+    hmix_constant=0, visc2=0.0, tnu2=(0.0, 0.0, 0.0), u_0=0.0, v_0=0.0, z0=0.1, zRef=80.0, uRef=0.0,
 )
 
 CASES = {
@@ -33,7 +33,14 @@ CASES = {
     "Advection": dict(_DEFAULTS, prob="Advection", ncell=(81, 81, 16), prob_lo=(0., 0., -150.), prob_hi=(41000., 41000., 0.),
                       periodic=(1, 1), fixed_dt=300.0, ndtfast=30, use_coriolis=0, flat_bathymetry=1, R0=1027.0, S0=35.0,
                       T0=14.0, Tcoef=1.7e-4, Scoef=0.0, rho0=1025.0, u_0=1.0e-1, v_0=-1.0e-1),
+    # Tests/test_files/DoublyPeriodic/DoublyPeriodic.i (Exec/DoublyPeriodic: log-layer x-velocity, scalar disc, flat bottom)
+    "DoublyPeriodic": dict(_DEFAULTS, prob="DoublyPeriodic", ncell=(41, 80, 16), prob_lo=(0., 0., -150.), prob_hi=(41000., 80000., 0.),
+                           periodic=(1, 1), fixed_dt=300.0, ndtfast=30, flat_bathymetry=1, R0=1027.0, S0=35.0, T0=14.0,
+                           Tcoef=1.7e-4, Scoef=0.0, rho0=1025.0, use_coriolis=1, coriolis_f0=-8.26e-5, coriolis_beta=0.0,
+                           u_0=0.0, v_0=0.0, z0=0.1, zRef=80.0e-3, uRef=8.0e-3),
 }
+# Tests/test_files/DoublyPeriodic_bathy/DoublyPeriodic_bathy.i: the same with remora.flat_bathymetry = false
+CASES["DoublyPeriodic_bathy"] = dict(CASES["DoublyPeriodic"], flat_bathymetry=0)
 
 
 def get(name):

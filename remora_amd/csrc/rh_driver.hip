@@ -221,7 +221,7 @@ extern "C" int rh_advance(rh_ctx *c, rh_state *s, int istep, double t_old)
 // ------------------------------------------------------------------------------------------------------------------
 // Synthetic initial state: REMORA::init_only (Source/REMORA.cpp:608-702), set_2darrays (Initialization/REMORA_init.cpp:97-154),
 // set_pm_pn (REMORA_make_new_level.cpp:548-553), init_custom_{bathymetry,prob,hmix,smflux} of Exec/<case>/prob.cpp
-struct InitPar { int prob, nx, ny, perx, pery, flat, use_salt; double plo[3], phi[3], dx0, dx1, T0, S0, rho0, g, u0, v0; };
+struct InitPar { int prob, nx, ny, perx, pery, flat, use_salt; double plo[3], phi[3], dx0, dx1, T0, S0, rho0, g, u0, v0, z0, zRef, uRef; };
 
 __global__ void k_init_h(B3 b, A4 h, InitPar q)
 {
@@ -245,6 +245,17 @@ __global__ void k_init_h(B3 b, A4 h, InitPar q)
             h(i, j, 0, 0) = depth - 4500.0 * exp(-(val1 * val1 + val2 * val2));
         } else { h(i, j, 0, 0) = -q.plo[2]; h(i, j, 0, 1) = -q.plo[2]; }
     } else if (q.prob == 3) { h(i, j, 0, 0) = -q.plo[2]; h(i, j, 0, 1) = -q.plo[2]; }   // Exec/Advection/prob.cpp:29-52
+    else if (q.prob == 4) {                                                    // Exec/DoublyPeriodic/prob.cpp:32-105
+        const int Lm = q.nx, Mm = q.ny;
+        if (q.flat) { h(i, j, 0, 0) = -q.plo[2]; h(i, j, 0, 1) = -q.plo[2]; }
+        else if (q.pery) {
+            const int iFort = i + 1; const double val1 = (iFort <= Lm / 2.0) ? iFort : Lm + 1 - iFort;
+            h(i, j, 0, 0) = dmin_(-q.plo[2], (84.5 + 66.526 * tanh((val1 - 10.0) / 7.0)));
+        } else if (q.perx) {
+            const int jFort = j + 1; const double val1 = (jFort <= Mm / 2.0) ? jFort : Mm + 1 - jFort;
+            h(i, j, 0, 0) = dmin_(-q.plo[2], (84.5 + 66.526 * tanh((val1 - 10.0) / 7.0)));
+        }
+    }
 }
 __global__ void k_init_cons(B3 b, A4 st, A4 z_r, InitPar q)
 {
@@ -262,6 +273,13 @@ __global__ void k_init_cons(B3 b, A4 st, A4 z_r, InitPar q)
         st(i, j, k, 0) = val3 - 3.0 * val4;
         if (q.use_salt) st(i, j, k, 1) = 34.5 - 0.001 * z - val4;
         st(i, j, k, 2) = 0.0;
+    } else if (q.prob == 4) {                                                  // DoublyPeriodic/prob.cpp:126-180
+        st(i, j, k, 0) = q.T0 + 8.0 * exp(z / 50.0);
+        if (q.use_salt) st(i, j, k, 1) = q.S0;
+        const double xcent = 0.5 * (q.plo[0] + q.phi[0]), ycent = 0.5 * (q.plo[1] + q.phi[1]);
+        const double x = q.plo[0] + (i + 0.5) * q.dx0 - xcent, y = q.plo[1] + (j + 0.5) * q.dx1 - ycent;
+        const double r2 = x * x + y * y, rad = 0.1 * (q.phi[0] - q.plo[0]), radsq = rad * rad;
+        st(i, j, k, 2) = (r2 < radsq) ? 1.0 : 0.0;
     } else {                                                                   // Advection/prob.cpp:72-157
         st(i, j, k, 0) = q.T0;
         const double xcent = 0.5 * (q.plo[0] + q.phi[0]), ycent = 0.5 * (q.plo[1] + q.phi[1]);
@@ -270,6 +288,14 @@ __global__ void k_init_cons(B3 b, A4 st, A4 z_r, InitPar q)
         if (q.use_salt) st(i, j, k, 1) = q.S0;
         st(i, j, k, 2) = exp(-r2 / (2. * radsq));
     }
+}
+// log-layer x-velocity of Exec/DoublyPeriodic/prob.cpp:182-198 (z_r of the cell to the right of the face, as the reference indexes it)
+__global__ void k_init_u_log(B3 b, A4 u, A4 z_r, InitPar q)
+{
+    RH_IJ(b); if (!inb2(b, i, j)) return;
+    const int k = b.lo2 + RH_KZ;
+    const double z = -z_r(i, j, k);
+    u(i, j, k) = q.u0 + q.uRef * log((z + q.z0) / q.z0) / log((q.zRef + q.z0) / q.z0);
 }
 __global__ void k_setbox(B3 b, A4 a, double v)
 {
@@ -322,13 +348,13 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
     const rh_params &P = c->prm;
     const int N = c->N;
     const rh_box bx = c->bx, b2 = bx_slab(bx, 2, 0);
-    if (ip->prob < 0 || ip->prob > 3) return rh_fail("rh_init_state: unknown problem %d", ip->prob);
+    if (ip->prob < 0 || ip->prob > 4) return rh_fail("rh_init_state: unknown problem %d", ip->prob);
     InitPar q; memset(&q, 0, sizeof q);
     q.prob = ip->prob; q.nx = c->dom.hi[0] - c->dom.lo[0] + 1; q.ny = c->dom.hi[1] - c->dom.lo[1] + 1;
     q.perx = P.periodic[0]; q.pery = P.periodic[1]; q.flat = P.flat_bathymetry; q.use_salt = P.use_salt;
     for (int d = 0; d < 3; d++) { q.plo[d] = P.prob_lo[d]; q.phi[d] = P.prob_hi[d]; }
     q.dx0 = (P.prob_hi[0] - P.prob_lo[0]) / q.nx; q.dx1 = (P.prob_hi[1] - P.prob_lo[1]) / q.ny;
-    q.T0 = P.T0; q.S0 = P.S0; q.rho0 = P.rho0; q.g = P.g; q.u0 = ip->u_0; q.v0 = ip->v_0;
+    q.T0 = P.T0; q.S0 = P.S0; q.rho0 = P.rho0; q.g = P.g; q.u0 = ip->u_0; q.v0 = ip->v_0; q.z0 = ip->z0; q.zRef = ip->zRef; q.uRef = ip->uRef;
     const double dxi0 = q.nx / (P.prob_hi[0] - P.prob_lo[0]), dxi1 = q.ny / (P.prob_hi[1] - P.prob_lo[1]);
 
     // everything starts at zero (the reference poisons fresh FABs with signalling NaNs and then sets what it reads)
@@ -346,7 +372,7 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
     if (ip->prob == 2) RH_TRY(dev_setval(c, s->h, 0, 2, 500.0));                                   // DoubleGyre/prob.cpp:21-28
     else {
         RH_TRY(dev_setval(c, s->h, 0, 2, P.prob_hi[2]));
-        rh_box hb = (ip->prob == 0) ? bx_grow(b2, 2, 2, 0) : (ip->prob == 1 ? bx_grow(b2, 3, 3, 0) : bx_of(s->h));
+        rh_box hb = (ip->prob == 0 || ip->prob == 4) ? bx_grow(b2, 2, 2, 0) : (ip->prob == 1 ? bx_grow(b2, 3, 3, 0) : bx_of(s->h));
         hb = bx_and(hb, bx_of(s->h));
         k_init_h<<<grid2(hb), rh_block(), 0, c->stream>>>(mkB(hb), mkA(s->h), q);
         RH_LAUNCH_CHECK();
@@ -357,8 +383,13 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
     // init_custom_prob
     k_init_cons<<<grid3(bx), rh_block(), 0, c->stream>>>(mkB(bx), mkA(s->cons_new), mkA(s->z_r), q);
     RH_LAUNCH_CHECK();
-    RH_TRY(setbox(c, s->xvel_new, 0, bx_nodal(bx, 0), ip->prob == 3 ? ip->u_0 : 0.0));
-    RH_TRY(setbox(c, s->yvel_new, 0, bx_nodal(bx, 1), ip->prob == 3 ? ip->v_0 : 0.0));
+    if (ip->prob == 4) {
+        const rh_box xb = bx_nodal(bx, 0);
+        RH_NEED(s->xvel_new, xb); RH_NEED(s->z_r, xb);
+        k_init_u_log<<<grid3(xb), rh_block(), 0, c->stream>>>(mkB(xb), mkA(s->xvel_new), mkA(s->z_r), q);
+        RH_LAUNCH_CHECK();
+    } else RH_TRY(setbox(c, s->xvel_new, 0, bx_nodal(bx, 0), ip->prob == 3 ? ip->u_0 : 0.0));
+    RH_TRY(setbox(c, s->yvel_new, 0, bx_nodal(bx, 1), (ip->prob == 3 || ip->prob == 4) ? ip->v_0 : 0.0));
     RH_TRY(dev_setval(c, s->pm, 0, 1, dxi0)); RH_TRY(dev_setval(c, s->pn, 0, 1, dxi1));            // set_pm_pn
     {                                                                                              // set_2darrays
         const rh_box ub = bx_grow(bx_nodal(b2, 0), 2, 2, 0), vb = bx_grow(bx_nodal(b2, 1), 2, 2, 0), un = bx_union(ub, vb);
@@ -373,7 +404,7 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
     {                                                                                              // set_hmixcoef, REMORA.cpp:575-596
         double v = 0.0, d[RH_NCONS] = {0.0, 0.0, 0.0};
         if (ip->hmix_constant) { v = ip->visc2; for (int n = 0; n < RH_NCONS; n++) d[n] = ip->tnu2[n]; }
-        else if (ip->prob == 0 || ip->prob == 3) v = 5.0;
+        else if (ip->prob == 0 || ip->prob == 3 || ip->prob == 4) v = 5.0;
         else if (ip->prob == 2) { v = 1280.0; for (int n = 0; n < RH_NCONS; n++) d[n] = 1280.0; }
         RH_TRY(dev_setval(c, s->visc2_p, 0, 1, v)); RH_TRY(dev_setval(c, s->visc2_r, 0, 1, v));
         for (int n = 0; n < RH_NCONS; n++) RH_TRY(dev_setval(c, s->diff2, n, 1, d[n]));

@@ -67,7 +67,8 @@ class State(C.Structure):
 
 class InitParams(C.Structure):
     _fields_ = [("prob", C.c_int), ("rdrag", C.c_double), ("coriolis_f0", C.c_double), ("coriolis_beta", C.c_double),
-                ("hmix_constant", C.c_int), ("visc2", C.c_double), ("tnu2", C.c_double * NCONS), ("u_0", C.c_double), ("v_0", C.c_double)]
+                ("hmix_constant", C.c_int), ("visc2", C.c_double), ("tnu2", C.c_double * NCONS), ("u_0", C.c_double), ("v_0", C.c_double),
+                ("z0", C.c_double), ("zRef", C.c_double), ("uRef", C.c_double)]
 
 
 class HaloPlan(C.Structure):

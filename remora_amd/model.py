@@ -38,7 +38,7 @@ def make_params(case, box=None, nranks=(1, 1), rank_xy=(0, 0)):
         setattr(p, k, case[k])
     prob = case["prob"]
     # init_custom_vmix / init_custom_smflux of Exec/<case>/prob.cpp
-    if prob in ("Upwelling", "Advection"):
+    if prob in ("Upwelling", "Advection", "DoublyPeriodic"):
         p.vmix_mode = L.VMIX_UPWELLING
     else:
         p.vmix_mode = L.VMIX_CONST
@@ -48,7 +48,7 @@ def make_params(case, box=None, nranks=(1, 1), rank_xy=(0, 0)):
         p.Akt_const[1] = akt
         p.Akt_const[2] = 0.0
     p.smflux_mode = {"Upwelling": L.SMFLUX_UPWELLING, "Seamount": L.SMFLUX_NONE, "Advection": L.SMFLUX_NONE,
-                     "DoubleGyre": L.SMFLUX_FIXED}[prob]
+                     "DoubleGyre": L.SMFLUX_FIXED, "DoublyPeriodic": L.SMFLUX_UPWELLING}[prob]
     p.masks_all_one = int(case.get("masks_all_one", 1))      # every pinned case has mask == 1 (make_new_level.cpp:381-389)
     return p
 
@@ -65,6 +65,9 @@ def make_init_params(case):
         ip.tnu2[n] = case["tnu2"][n]
     ip.u_0 = case["u_0"]
     ip.v_0 = case["v_0"]
+    ip.z0 = case["z0"]
+    ip.zRef = case["zRef"]
+    ip.uRef = case["uRef"]
     return ip
 
 

@@ -32,7 +32,7 @@ def _check(res, case, what):
         assert not bad, f"{case} {what}: beyond {RTOL_STEP}: {bad}"
 
 
-@pytest.mark.parametrize("case", ["Seamount", "DoubleGyre", "Upwelling", "Advection"])
+@pytest.mark.parametrize("case", ["Seamount", "DoubleGyre", "Upwelling", "Advection", "DoublyPeriodic", "DoublyPeriodic_bathy"])
 def test_phases_against_oracle(case):
     """Three baroclinic steps from the oracle's initial state (covers the iic = 0, 1, >= 2 branches), comparing all
     fields incl. ghost cells after setup_step, after the barotropic loop and after advance_3d_ml."""
@@ -83,7 +83,7 @@ def test_mask_reading_path(case):
     rem.close(); orc.close()
 
 
-@pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection"])
+@pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection", "DoublyPeriodic", "DoublyPeriodic_bathy"])
 def test_gold_plotfile(case):
     """Device-side initial state + ten steps through REMORA::Advance == the reference's regression test."""
     names, gold = read_plotfile(case)
