@@ -35,29 +35,28 @@ __device__ __forceinline__ double a3_tflux_w(const A4 &t, int i, int j, int kk, 
 // reference evaluates cosh/exp at every (i,j,k).  sc = [sc_w | Cs_w | sc_r | Cs_r], each nz+1 long.
 __global__ void k_stretch(B3 b, A4 z_w, A4 z_r, A4 Hz, A4 h, A4 Zt, const double *__restrict__ sc, int nz, double hc)
 {
-    // one thread per (i,j,k): no level depends on another (each thread rebuilds the two faces of its cell with the expressions of
-    // the column loop, so the bits are the same), and a write-only kernel wants every lane storing at once
     RH_IJ(b); if (!inb2(b, i, j)) return;
-    const int k = RH_KZ;                                   // 0 .. nz-1
     const double *sc_w = sc, *Cs_w = sc + (nz + 1), *sc_r = sc + 2 * (nz + 1), *Cs_r = sc + 3 * (nz + 1);
     const double hwater = h(i, j, 0, 0);
     const double hinv = 1.0 / (hc + hwater);
     const double zt = Zt(i, j, 0);
-    auto face = [&](int kk) -> double {
-        const double cff_w = hc * sc_w[kk], cff1_w = Cs_w[kk];
+    double zw_prev = 0.0;
+    for (int k = 0; k <= nz; k++) {
+        const double cff_w = hc * sc_w[k], cff1_w = Cs_w[k];
         const double cff2_w = (cff_w + cff1_w * hwater) * hinv;
-        return kk == nz ? zt : zt + (zt + hwater) * cff2_w;
-    };
-    const double zw0 = face(k), zw1 = face(k + 1);
-    if (k == 0) h(i, j, 0, 1) = zw0;
-    z_w(i, j, k) = zw0;
-    if (k == nz - 1) z_w(i, j, nz) = zw1;
-    {
-        const double cff_r = hc * sc_r[k], cff1_r = Cs_r[k];
-        const double cff2_r = (cff_r + cff1_r * hwater) * hinv;
-        z_r(i, j, k) = zt + (zt + hwater) * cff2_r;
+        double zw;
+        if (k == nz) zw = zt;
+        else zw = zt + (zt + hwater) * cff2_w;
+        if (k == 0) h(i, j, 0, 1) = zw;
+        z_w(i, j, k) = zw;
+        if (k != nz) {
+            const double cff_r = hc * sc_r[k], cff1_r = Cs_r[k];
+            const double cff2_r = (cff_r + cff1_r * hwater) * hinv;
+            z_r(i, j, k) = zt + (zt + hwater) * cff2_r;
+        }
+        if (k > 0) Hz(i, j, k - 1) = zw - zw_prev;
+        zw_prev = zw;
     }
-    Hz(i, j, k) = zw1 - zw0;
 }
 extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
 {
@@ -69,7 +68,7 @@ extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
     RH_NEED(s->z_w, bw); RH_NEED(s->z_r, b); RH_NEED(s->Hz, b); RH_NEED(s->h, b2); RH_NEED(s->Zt_avg1, b2);
     if (s->h.ncomp < 2) return rh_fail("rh_stretch_transform: h needs 2 components");
     const double hc = -std::min(c->prm.prob_hi[2], -c->prm.tcline);                          // :51
-    k_stretch<<<grid3(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(s->z_w), mkA(s->z_r), mkA(s->Hz), mkA(s->h), mkA(s->Zt_avg1), c->d_sc, nz, hc);
+    k_stretch<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(s->z_w), mkA(s->z_r), mkA(s->Hz), mkA(s->h), mkA(s->Zt_avg1), c->d_sc, nz, hc);
     RH_LAUNCH_CHECK();
     BcScope xs(c);                                                                           // one message per neighbour for the three
     RH_TRY(halo_fill_boundary(c, mfv(c, s->z_w, 0, 0, 1), 0, 1));                            // :198-201
