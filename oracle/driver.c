@@ -29,6 +29,7 @@ struct OState {
     MF z_w,z_r,Hz,Huon,Hvom,Akv,Akt,visc2_p,visc2_r,diff2;
     MF rufrc,rvfrc,sustr,svstr,rdrag,bustr,bvstr,DU_avg1,DU_avg2,DV_avg1,DV_avg2,rubar,rvbar,rzeta,zeta;
     MF pm,pn,fcor,sstore,rhoS,rhoA,bvf;
+    MF tke,gls,Lscale,Akk,Akp;   /* GLS closure, make_new_level.cpp:499-503 */
 };
 
 #define F(m) ((s)->m.f)
@@ -220,6 +221,20 @@ static void set_analytical_vmix(OState *s)
     for(int n=0;n<NCONS;n++) o_fillpatch(&s->geom,&s->Akt,F(mskr),BCV_ZVEL,0,1);
 }
 
+/* REMORA::init_gls_vmix, Initialization/REMORA_init.cpp:156-190 */
+static void init_gls_vmix(OState *s)
+{
+    const GlsParams *G=&s->prm.gls; int N=s->N;
+    fab_setval(F(tke),G->Kmin); fab_setval(F(gls),G->Pmin); fab_setval(F(Lscale),0.0);
+    fab_setval(F(Akk),G->Akk_bak); fab_setval(F(Akp),G->Akp_bak); fab_setval(F(Akv),G->Akv_bak); fab_setval(F(Akt),G->Akt_bak);
+    Fab Akk=F(Akk), Akp=F(Akp), Akv=F(Akv), Akt=F(Akt);
+    Box b=box_slab(fab_box(Akk),2,0);
+    FORBOX2D(b,i,j){
+        V(Akk,i,j,0)=0.0; V(Akk,i,j,N+1)=0.0; V(Akp,i,j,0)=0.0; V(Akp,i,j,N+1)=0.0;
+        V(Akv,i,j,0)=0.0; V(Akv,i,j,N+1)=0.0; V(Akt,i,j,0)=0.0; V(Akt,i,j,N+1)=0.0;      /* Akt: component 0 only */
+    }
+}
+
 static void init_hmix(OState *s)
 {
     const Params *P=&s->prm; Fab vp=F(visc2_p), vr=F(visc2_r), d2=F(diff2);
@@ -311,6 +326,10 @@ OState* o_create(const Params *prm)
     s->pm=mf_alloc(b2,0,0,0,1,G+1,G+2,0); s->pn=mf_alloc(b2,0,0,0,1,G+2,G+1,0); s->fcor=mf_alloc(b2,0,0,0,1,G+1,G+1,0);
     s->sstore=mf_alloc(b3,0,0,0,NCONS,G,G,0);
     s->rhoS=mf_alloc(b2,0,0,0,1,G,G,0); s->rhoA=mf_alloc(b2,0,0,0,1,G,G,0); s->bvf=mf_alloc(b3,0,0,1,1,G,G,0);
+    s->tke=mf_alloc(b3,0,0,1,3,G,G,0); s->gls=mf_alloc(b3,0,0,1,3,G,G,0); s->Lscale=mf_alloc(b3,0,0,1,1,G,G,0);
+    s->Akk=mf_alloc(b3,0,0,1,1,G,G,0); s->Akp=mf_alloc(b3,0,0,1,1,G,G,0);
+    fab_setval(F(tke),P->gls.Kmin); fab_setval(F(gls),P->gls.Pmin); fab_setval(F(Lscale),0.0);         /* make_new_level.cpp:517-521 */
+    fab_setval(F(Akk),P->gls.Akk_bak); fab_setval(F(Akp),P->gls.Akp_bak);
 
     s->weight1=(double*)calloc(2*P->ndtfast+1,sizeof(double)); s->weight2=(double*)calloc(2*P->ndtfast+1,sizeof(double));
     s->nfast=o_set_weights(P->ndtfast,s->weight1,s->weight2);                  /* make_new_level.cpp:505 */
@@ -344,7 +363,7 @@ OState* o_create(const Params *prm)
       o_fillpatch(&s->geom,&s->ubar,F(msku),BCV_UBAR,0,1);
       o_fillpatch(&s->geom,&s->vbar,F(mskv),BCV_VBAR,0,1);
     }
-    set_analytical_vmix(s);                                                    /* init_set_vmix */
+    if(P->gls.on) init_gls_vmix(s); else set_analytical_vmix(s);               /* init_set_vmix, REMORA.cpp:550-562 */
     init_hmix(s);                                                              /* set_hmixcoef */
     if(P->use_coriolis){                                                       /* set_coriolis :528-549, REMORA_init.cpp:48-74 */
         Fab fc=F(fcor); Box b=fab_box(fc);
@@ -373,7 +392,8 @@ void o_destroy(OState *s)
         &s->Zt_avg1,&s->h,&s->ubar,&s->vbar,&s->ru,&s->rv,&s->ru2d,&s->rv2d,&s->mskr,&s->msku,&s->mskv,&s->mskp,
         &s->z_w,&s->z_r,&s->Hz,&s->Huon,&s->Hvom,&s->Akv,&s->Akt,&s->visc2_p,&s->visc2_r,&s->diff2,
         &s->rufrc,&s->rvfrc,&s->sustr,&s->svstr,&s->rdrag,&s->bustr,&s->bvstr,&s->DU_avg1,&s->DU_avg2,&s->DV_avg1,&s->DV_avg2,
-        &s->rubar,&s->rvbar,&s->rzeta,&s->zeta,&s->pm,&s->pn,&s->fcor,&s->sstore,&s->rhoS,&s->rhoA,&s->bvf};
+        &s->rubar,&s->rvbar,&s->rzeta,&s->zeta,&s->pm,&s->pn,&s->fcor,&s->sstore,&s->rhoS,&s->rhoA,&s->bvf,
+        &s->tke,&s->gls,&s->Lscale,&s->Akk,&s->Akp};
     for(unsigned q=0;q<sizeof(all)/sizeof(all[0]);q++) mf_free(all[q]);
     free(s->weight1); free(s->weight2); free(s);
 }
@@ -450,7 +470,7 @@ void o_setup_step(OState *s)
         FORBOX(bv,i,j,k){ double om_v=2.0/(V(pm,i,j-1,0)+V(pm,i,j,0)); V(Hvom,i,j,k)=0.5*(V(Hz,i,j,k)+V(Hz,i,j-1,k))*V(vold,i,j,k)*om_v; }
         o_rho_eos(g,box_grow(bx,NGROW,NGROW,0),F(cons_old),mf_rho.f,F(rhoA),F(rhoS),F(bvf),Hz,F(z_w),F(z_r),F(h),F(mskr),N);
     }
-    set_analytical_vmix(s);                                                    /* :203-206 */
+    if(!P->gls.on) set_analytical_vmix(s);                                     /* :202-205 */
     { Box b=box_slab(box_grow(bx,NGROW+1,NGROW+1,0),2,0); Fab ze=F(zeta), Zt=F(Zt_avg1);   /* set_zeta_to_Ztavg :208 */
       for(int n=0;n<3;n++) FORBOX2D(b,i,j) VN(ze,i,j,0,n)=V(Zt,i,j,0); }
     MF mf_W=mf_alloc(bx,0,0,1,1,NGROW+1,NGROW+1,0); fab_setval(mf_W.f,0.0);    /* :210-211 */
@@ -476,6 +496,14 @@ void o_setup_step(OState *s)
             o_uv3dmix(xbx,ybx,F(xvel_new),F(yvel_new),F(xvel_old),F(yvel_old),F(rufrc),F(rvfrc),F(visc2_p),F(visc2_r),F(Hz),
                       F(pm),F(pn),F(mskp),nrhs,0,dt_lev);
         fab_free(&FC); fab_free(&fomn);
+    }
+    if(P->gls.on){                                                             /* :352-357 */
+        int nnew_g=(iic+1)%2, nstp_g=iic%2;
+        o_gls_prestep(g,bx,F(gls),F(tke),mf_W.f,F(Huon),F(Hvom),F(Hz),F(pm),F(pn),F(msku),F(mskv),nstp_g,nnew_g,iic,ntfirst,N,dt_lev);
+        for(int ic=0;ic<3;ic++){                                               /* REMORA_gls.cpp:212-215 */
+            o_fillpatch(g,&s->tke,F(mskr),BCV_ZVEL,ic,1);
+            o_fillpatch(g,&s->gls,F(mskr),BCV_ZVEL,ic,1);
+        }
     }
     o_fillpatch(g,&s->sstore,F(mskr),BCV_CONS,0,NCONS);                         /* :363 */
     o_fill_boundary(g,&s->Huon,0,1);                                           /* :367-368 */
@@ -762,6 +790,18 @@ static void advance_3d(OState *s)
     }
     MF mf_W=mf_alloc(bx,0,0,1,1,NGROW+1,NGROW+1,0); fab_setval(mf_W.f,0.0);    /* :230-294 */
     o_omega(gbx1,mf_W.f,F(Huon),F(Hvom),F(z_w),F(h),N);
+    if(s->prm.gls.on){                                                         /* :296-303 */
+        int nstp_g=iic%2, nnew_g=1-nstp_g;
+        o_gls_corrector(g,bx,F(gls),F(tke),mf_W.f,F(Akv),F(Akt),F(Akk),F(Akp),F(Lscale),F(mskr),F(msku),F(mskv),Hz,
+                        F(xvel_old),F(yvel_old),pm,pn,F(Huon),F(Hvom),F(z_w),F(sustr),F(svstr),F(bustr),F(bvstr),F(bvf),
+                        nstp_g,nnew_g,N,dt_lev);
+        for(int ic=0;ic<3;ic++){                                               /* REMORA_gls.cpp:905-914 */
+            o_fillpatch(g,&s->tke,F(mskr),BCV_ZVEL,ic,1);
+            o_fillpatch(g,&s->gls,F(mskr),BCV_ZVEL,ic,1);
+        }
+        for(int ic=0;ic<NCONS;ic++) o_fillpatch(g,&s->Akt,F(mskr),BCV_ZVEL,ic,1);
+        o_fill_boundary(g,&s->Akv,0,1); o_fill_boundary(g,&s->Akp,0,1); o_fill_boundary(g,&s->Akk,0,1);
+    }
     {
         Fab FC=fab_alloc(box_nodal(gbx2,2),1);                                 /* :306-348 */
         Box gbx=box_grow(bx,3,3,3);
@@ -828,6 +868,7 @@ int o_field(OState *s,const char *name,double **p,int lo[3],int hi[3],int *nc)
     FLD(z_w) FLD(z_r) FLD(Hz) FLD(Huon) FLD(Hvom) FLD(Akv) FLD(Akt) FLD(visc2_p) FLD(visc2_r) FLD(diff2)
     FLD(rufrc) FLD(rvfrc) FLD(sustr) FLD(svstr) FLD(rdrag) FLD(bustr) FLD(bvstr) FLD(DU_avg1) FLD(DU_avg2) FLD(DV_avg1) FLD(DV_avg2)
     FLD(rubar) FLD(rvbar) FLD(rzeta) FLD(zeta) FLD(pm) FLD(pn) FLD(fcor) FLD(sstore) FLD(rhoS) FLD(rhoA) FLD(bvf)
+    FLD(tke) FLD(gls) FLD(Lscale) FLD(Akk) FLD(Akp)
 #undef FLD
     if(!strcmp(name,"weight1")){ *p=s->weight1; lo[0]=lo[1]=lo[2]=0; hi[0]=2*s->prm.ndtfast; hi[1]=hi[2]=0; *nc=1; return 1; }
     if(!strcmp(name,"weight2")){ *p=s->weight2; lo[0]=lo[1]=lo[2]=0; hi[0]=2*s->prm.ndtfast; hi[1]=hi[2]=0; *nc=1; return 1; }

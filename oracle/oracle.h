@@ -26,6 +26,10 @@ typedef struct { int lo[3], hi[3]; } BCRec;
 
 enum { CASE_UPWELLING=0, CASE_SEAMOUNT=1, CASE_DOUBLEGYRE=2, CASE_ADVECTION=3, CASE_DOUBLYPERIODIC=4 };
 
+/* vertical_mixing_type = gls: SolverChoice's GLS block, Source/REMORA_DataStruct.H:203-268,399-400,427-445
+ * stab: 0 Canuto_A, 1 Canuto_B, 2 Galperin */
+typedef struct { int on, stab; double p,m,n,Kmin,Pmin,cmu0,c1,c2,c3m,c3p,sigk,sigp,Akk_bak,Akp_bak,Akv_bak,Akt_bak,Zos,Zob; } GlsParams;
+
 typedef struct {
     /* geometry */
     int    ncell[3];
@@ -45,6 +49,7 @@ typedef struct {
     int    prob;                 /* CASE_* */
     double u_0, v_0;             /* Advection / DoublyPeriodic prob.u_0 / prob.v_0 */
     double z0, zRef, uRef;       /* DoublyPeriodic prob.z0 / prob.zRef / prob.uRef (log-layer x-velocity) */
+    GlsParams gls;
     int    threads;              /* OpenMP threads for the timing baseline (0/1 = serial) */
 } Params;
 
@@ -95,6 +100,13 @@ void o_fill_boundary(const Geom*,MF *mf,int icomp,int ncomp);     /* single-box 
 void o_physbc(const Geom*,MF *mf,Fab msk,int icomp,int ncomp,int bccomp,int n_not_fill);
 /* REMORA::FillPatch at level 0 == FillBoundary + physbc (BoundaryConditions/REMORA_FillPatch.cpp:96-125) */
 void o_fillpatch(const Geom*,MF *mf,Fab msk,int bccomp,int icomp,int ncomp);
+
+/* ---- GLS closure (gls.c) ---- */
+void o_gls_prestep(const Geom*,Box vbx,Fab gls,Fab tke,Fab W,Fab Huon,Fab Hvom,Fab Hz,Fab pm,Fab pn,Fab msku,Fab mskv,
+                   int nstp,int nnew,int iic,int ntfirst,int N,double dt_lev);
+void o_gls_corrector(const Geom*,Box vbx,Fab gls,Fab tke,Fab W,Fab Akv,Fab Akt,Fab Akk,Fab Akp,Fab Lscale,Fab mskr,Fab msku,Fab mskv,
+                     Fab Hz,Fab u,Fab v,Fab pm,Fab pn,Fab Huon,Fab Hvom,Fab z_w,Fab sustr,Fab svstr,Fab bustr,Fab bvstr,Fab bvf,
+                     int nstp,int nnew,int N,double dt_lev);
 
 /* ---- driver (driver.c) ---- */
 typedef struct OState OState;

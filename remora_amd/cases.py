@@ -6,6 +6,7 @@ the SolverChoice defaults of Source/REMORA_DataStruct.H:351-483 it leaves untouc
 """
 import copy
 
+GLS_STAB = {"Canuto_A": 0, "Canuto_B": 1, "Galperin": 2}
 PROB = {"Upwelling": 0, "Seamount": 1, "DoubleGyre": 2, "Advection": 3, "DoublyPeriodic": 4}
 
 _DEFAULTS = dict(
@@ -41,6 +42,12 @@ CASES = {
 }
 # Tests/test_files/DoublyPeriodic_bathy/DoublyPeriodic_bathy.i: the same with remora.flat_bathymetry = false
 CASES["DoublyPeriodic_bathy"] = dict(CASES["DoublyPeriodic"], flat_bathymetry=0)
+
+# Tests/test_files/Upwelling_GLS/Upwelling_GLS.i: Upwelling with remora.vertical_mixing_type = "gls" (galperin stability, the
+# k-epsilon exponents); values the input leaves out are the SolverChoice defaults (REMORA_DataStruct.H:399-400,427-445)
+CASES["Upwelling_GLS"] = dict(CASES["Upwelling"], gls=dict(
+    stab="Galperin", p=3.0, m=1.5, n=-1.0, Kmin=7.6e-6, Pmin=1.0e-12, cmu0=0.5477, c1=1.44, c2=1.92, c3m=-0.4, c3p=1.0,
+    sigk=1.0, sigp=1.3, Akk_bak=5.0e-6, Akp_bak=5.0e-6, Akv_bak=1.0e-5, Akt_bak=1.0e-6, Zos=2e-2, Zob=2e-2))
 
 
 def get(name):
