@@ -35,7 +35,16 @@ enum { RH_BCV_CONS = 0, RH_BCV_XVEL = 3, RH_BCV_YVEL, RH_BCV_ZVEL, RH_BCV_UBAR, 
        RH_BCV_FOEXTRAP_PERIODIC, RH_BCV_FOEXTRAP, RH_BCV_U2D_SIMPLE, RH_BCV_V2D_SIMPLE, RH_BCV_NUM };
 /* analytic vertical mixing profiles = the init_custom_vmix hooks of Exec/<case>/prob.cpp that set_analytical_vmix
  * (Source/REMORA.cpp:565-573) calls from setup_step every step */
-enum { RH_VMIX_CONST = 0, RH_VMIX_UPWELLING = 1 };
+enum { RH_VMIX_CONST = 0, RH_VMIX_UPWELLING = 1,
+       RH_VMIX_GLS = 2 };   /* remora.vertical_mixing_type = gls: Akv / Akt come from the closure (rh_gls_*), not from a profile */
+/* remora.gls_stability_type, Source/REMORA_DataStruct.H:206-224 */
+enum { RH_GLS_CANUTO_A = 0, RH_GLS_CANUTO_B = 1, RH_GLS_GALPERIN = 2 };
+/* SolverChoice's GLS block, Source/REMORA_DataStruct.H:203-204,228-268,399-400,427-445 (read only when vmix_mode = RH_VMIX_GLS) */
+typedef struct rh_gls_params {
+    int    stability;
+    double gls_p, gls_m, gls_n, gls_Kmin, gls_Pmin, gls_cmu0, gls_c1, gls_c2, gls_c3m, gls_c3p, gls_sigk, gls_sigp;
+    double Akk_bak, Akp_bak, Akv_bak, Akt_bak, Zos, Zob;
+} rh_gls_params;
 /* analytic surface momentum flux = init_custom_smflux hooks called by set_smflux (Source/REMORA.cpp:598-605) */
 enum { RH_SMFLUX_NONE = 0, RH_SMFLUX_UPWELLING = 1, RH_SMFLUX_FIXED = 2 };
 
@@ -54,6 +63,7 @@ typedef struct rh_params {
     int    vmix_mode;  double Akv_const, Akt_const[RH_NCONS];
     int    smflux_mode;
     int    masks_all_one;                /* 1: land/sea masks are identically 1 (all pinned cases); skips the final cons*=mskr pass */
+    rh_gls_params gls;
 } rh_params;
 
 /* One view per MultiFab the reference's drivers touch (Source/REMORA.H:189-354; shapes and ghost widths:
@@ -65,6 +75,9 @@ typedef struct rh_state {
     rh_array4 z_w, z_r, Hz, Huon, Hvom, Akv, Akt, visc2_p, visc2_r, diff2;
     rh_array4 rufrc, rvfrc, sustr, svstr, rdrag, bustr, bvstr, DU_avg1, DU_avg2, DV_avg1, DV_avg2;
     rh_array4 rubar, rvbar, rzeta, zeta, pm, pn, fcor, sstore, rhoS, rhoA, bvf;
+    /* GLS closure (make_new_level.cpp:499-503), w-points, ghost width 2: tke, gls x3 components (two time levels + predictor),
+     * Lscale, Akk, Akp.  Bound (and counted by rh_state_bytes) only when vmix_mode = RH_VMIX_GLS; null views otherwise. */
+    rh_array4 tke, gls, Lscale, Akk, Akp;
 } rh_state;
 
 typedef struct rh_ctx rh_ctx;
@@ -202,6 +215,17 @@ int  rh_advance(rh_ctx *ctx, rh_state *s, int istep, double t_old);
 void rh_swap_old_new(rh_state *s);
 
 /* ---- reductions around the step (REMORA::Evolve, Source/REMORA.cpp:139-212) ------------------------------ */
+/* ---- GLS turbulence closure (vmix_mode = RH_VMIX_GLS) ---- */
+/* REMORA::gls_prestep, TimeIntegration/REMORA_gls.cpp:5-216 (called from setup_step, REMORA_setup_step.cpp:352-357): predictor
+ * of tke and gls (component 2) and the Hz-weighted start of the new level (component nnew), then the six ghost fills of
+ * :212-215.  W = the omega array of the step (mf_W); nstp = iic % 2, nnew = (iic + 1) % 2. */
+int  rh_gls_prestep(rh_ctx *ctx, rh_state *s, rh_array4 W, int nstp, int nnew, int iic, int ntfirst);
+/* REMORA::gls_corrector, TimeIntegration/REMORA_gls.cpp:218-915 (called from advance_3d, REMORA_advance_3d.cpp:296-303):
+ * advances tke / gls to nnew and rebuilds Akv, Akt, Akk, Akp, Lscale, then the ghost fills of :905-914.  Reads xvel_old /
+ * yvel_old, Huon, Hvom, bvf, the surface and bottom stresses.  The per-point pow() calls run on device: results agree with
+ * the reference to rounding (tests: rel 1e-12 per step on the turbulence fields), not bit for bit. */
+int  rh_gls_corrector(rh_ctx *ctx, rh_state *s, rh_array4 W, int nstp, int nnew);
+
 /* REMORA::estTimeStep, TimeIntegration/REMORA_ComputeTimestep.cpp:39-95: max over the valid cells of |cell-centred velocity| / dx;
  * *dt_out = fixed dt (rh_params.dt) if that is > 0, else cfl / max (1e20 if the max is not positive).  Across the ranks of the
  * built-in RCCL communicator the max is all-reduced (ParallelDescriptor::ReduceRealMax, :66); local_only = 1 returns this rank's

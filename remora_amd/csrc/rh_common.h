@@ -142,6 +142,7 @@ struct rh_ctx {
     std::vector<double> h_sc; double *d_sc = nullptr;
     // device work space (replaces the per-call MultiFab / FArrayBox temporaries of the reference)
     rh_array4 rho, P, W, wCF, wDC, DUon, DVom, Drhs, Dnew, zwrk, gzeta, gzeta2, gzetaSA;
+    rh_array4 gW1, gW2, gW3, gS2C, gB2, gS2;      // GLS corrector scratch (allocated only with vmix_mode = RH_VMIX_GLS)
     double *d_work = nullptr; long work_bytes = 0;
     // RCCL
     void *comm = nullptr; int rank = 0, nranks = 1;
@@ -201,3 +202,5 @@ int  comm_exchange(rh_ctx *c, long n_lo, int peer_lo, long n_hi, int peer_hi);  
 // small utilities (rh_ctx.hip)
 int  dev_setval(rh_ctx *c, const rh_array4 &a, int icomp, int ncomp, double v);
 int  dev_copy(rh_ctx *c, const rh_array4 &dst, const rh_array4 &src);
+int  dev_setbox(rh_ctx *c, const rh_array4 &a, int comp, rh_box b, double v);      // rh_driver.hip
+int  launch_gls_init(rh_ctx *c, rh_state *s);                                      // rh_gls.hip

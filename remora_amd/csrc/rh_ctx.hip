@@ -199,7 +199,7 @@ static void init_bcs(rh_ctx *c)
 // kind: 0 = 3-D cell/face array over the full column, 1 = 2-D (k = 0 slab), 2 = k-limited coefficient array (k = 0..1:
 // visc2_p / visc2_r / diff2 are 3-D in the reference but only ever indexed at k = 0, and at k = 1 through the
 // 3-index access of REMORA_t3dmix.cpp:34,43)
-struct FieldSpec { rh_array4 rh_state::*m; int ix0, ix1, ix2, nc, ng0, ng1, kind; };
+struct FieldSpec { rh_array4 rh_state::*m; int ix0, ix1, ix2, nc, ng0, ng1, kind; int gls_only = 0; };
 static const FieldSpec g_fields[] = {
     {&rh_state::cons_old,0,0,0,RH_NCONS,3,3,0}, {&rh_state::cons_new,0,0,0,RH_NCONS,3,3,0},
     {&rh_state::xvel_old,1,0,0,1,3,3,0}, {&rh_state::xvel_new,1,0,0,1,3,3,0},
@@ -224,6 +224,9 @@ static const FieldSpec g_fields[] = {
     {&rh_state::pm,0,0,0,1,3,4,1}, {&rh_state::pn,0,0,0,1,4,3,1}, {&rh_state::fcor,0,0,0,1,3,3,1},
     {&rh_state::sstore,0,0,0,RH_NCONS,2,2,0},
     {&rh_state::rhoS,0,0,0,1,2,2,1}, {&rh_state::rhoA,0,0,0,1,2,2,1}, {&rh_state::bvf,0,0,1,1,2,2,0},
+    // GLS closure, make_new_level.cpp:499-503
+    {&rh_state::tke,0,0,1,3,2,2,0,1}, {&rh_state::gls,0,0,1,3,2,2,0,1}, {&rh_state::Lscale,0,0,1,1,2,2,0,1},
+    {&rh_state::Akk,0,0,1,1,2,2,0,1}, {&rh_state::Akp,0,0,1,1,2,2,0,1},
 };
 
 static rh_array4 shape_of(const rh_ctx *c, int ix0, int ix1, int ix2, int nc, int ng0, int ng1, int kind)
@@ -244,7 +247,10 @@ static inline long align32(long ndbl) { return (ndbl + 31) / 32 * 32; }    // 25
 extern "C" long rh_state_bytes(const rh_ctx *c)
 {
     long n = 0;
-    for (const FieldSpec &f : g_fields) n += align32(a4_size(shape_of(c, f.ix0, f.ix1, f.ix2, f.nc, f.ng0, f.ng1, f.kind)));
+    for (const FieldSpec &f : g_fields) {
+        if (f.gls_only && c->prm.vmix_mode != RH_VMIX_GLS) continue;
+        n += align32(a4_size(shape_of(c, f.ix0, f.ix1, f.ix2, f.nc, f.ng0, f.ng1, f.kind)));
+    }
     return n * 8;
 }
 extern "C" int rh_state_bind(const rh_ctx *c, void *device_base, rh_state *out)
@@ -252,6 +258,7 @@ extern "C" int rh_state_bind(const rh_ctx *c, void *device_base, rh_state *out)
     if (((size_t)device_base) & 255) return rh_fail("rh_state_bind: base must be 256-byte aligned");
     double *p = (double *)device_base;
     for (const FieldSpec &f : g_fields) {
+        if (f.gls_only && c->prm.vmix_mode != RH_VMIX_GLS) { rh_array4 z; memset(&z, 0, sizeof z); z.hi[0] = z.hi[1] = z.hi[2] = -1; out->*(f.m) = z; continue; }
         rh_array4 a = shape_of(c, f.ix0, f.ix1, f.ix2, f.nc, f.ng0, f.ng1, f.kind);
         a.p = p; p += align32(a4_size(a));
         out->*(f.m) = a;
@@ -317,7 +324,18 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     // 2-D intermediates of one advance_2d call (advance_2d.cpp:233-248): Drhs on grow 3, the rest on grow 2
     c->Drhs = shape_of(c, 0, 0, 0, 1, 3, 3, 1);
     c->Dnew = shape_of(c, 0, 0, 0, 1, 2, 2, 1); c->zwrk = c->Dnew; c->gzeta = c->Dnew; c->gzeta2 = c->Dnew; c->gzetaSA = c->Dnew;
-    rh_array4 *ws[] = {&c->rho, &c->P, &c->W, &c->wCF, &c->wDC, &c->DUon, &c->DVom, &c->Drhs, &c->Dnew, &c->zwrk, &c->gzeta, &c->gzeta2, &c->gzetaSA};
+    std::vector<rh_array4 *> ws = {&c->rho, &c->P, &c->W, &c->wCF, &c->wDC, &c->DUon, &c->DVom, &c->Drhs, &c->Dnew, &c->zwrk, &c->gzeta, &c->gzeta2, &c->gzetaSA};
+    if (prm->vmix_mode == RH_VMIX_GLS) {
+        // gls_corrector's scratch (REMORA_gls.cpp:355-376): three w-point arrays on the grow-1 box, the cached shear, buoy2, shear2
+        c->gW1 = shape_of(c, 0, 0, 1, 1, 1, 1, 0); c->gW2 = c->gW1; c->gW3 = c->gW1;
+        c->gS2C = shape_of(c, 0, 0, 0, 1, 2, 2, 0);
+        c->gB2 = shape_of(c, 0, 0, 0, 1, 0, 0, 0); c->gS2 = c->gB2;
+        for (rh_array4 *a : {&c->gW1, &c->gW2, &c->gW3, &c->gS2C, &c->gB2, &c->gS2}) ws.push_back(a);
+        const rh_gls_params &G = prm->gls;
+        if (G.stability < RH_GLS_CANUTO_A || G.stability > RH_GLS_GALPERIN) { (void)hipFree(c->d_sc); return bad("unknown gls stability type"); }
+        if (G.gls_n == 0.0 || !(G.gls_cmu0 > 0.0) || !(G.gls_sigk > 0.0) || !(G.gls_sigp > 0.0) || !(G.gls_Kmin > 0.0) || !(G.gls_Pmin > 0.0))
+            { (void)hipFree(c->d_sc); return bad("gls parameters: gls_n must be non-zero; cmu0, sigk, sigp, Kmin, Pmin positive"); }
+    }
     long n = 0; for (rh_array4 *a : ws) n += align32(a4_size(*a));
     c->work_bytes = n * 8;
     e = hipMalloc((void **)&c->d_work, c->work_bytes);

@@ -94,7 +94,7 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     { TScope t(c, "massflux_old"); RH_TRY(launch_massflux_old(c, s)); }                            // :187-197
     if (c->unfused) RH_TRY(rh_rho_eos(c, bx_grow(bx, 2, 2, 0), s->cons_old, c->rho, s->rhoA, s->rhoS, s->bvf, s->Hz, s->z_w, s->z_r, s->h, s->mskr, N));   // :200
     else RH_TRY(launch_rho_eos_P(c, s, bx_grow(bx, 2, 2, 0), bx_grow(bx, 1, 1, 0)));     // + the hydrostatic pressure of prsgrd (:229-260), same operands
-    RH_TRY(set_analytical_vmix(c, s));                                                             // :203-206
+    if (P.vmix_mode != RH_VMIX_GLS) RH_TRY(set_analytical_vmix(c, s));                             // :202-205
     RH_TRY(launch_set_zeta(c, s));                                                                 // :208
     // :210-211 mf_W.setVal(0): omega overwrites every level of the grow-1 box, so only the frame around it needs the zero
     if (P.use_prestep) RH_TRY(zero_outside(c, c->W, bx_grow(bx, 1, 1, 0))); else RH_TRY(dev_setval(c, c->W, 0, 1, 0.0));
@@ -132,6 +132,7 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     if (P.use_uv3dmix)
         RH_TRY(rh_uv3dmix(c, xbx, ybx, s->xvel_new, s->yvel_new, s->xvel_old, s->yvel_old, s->rufrc, s->rvfrc, s->visc2_p, s->visc2_r, s->Hz,
                           s->pm, s->pn, s->mskp, nrhs, 0, dt));
+    if (P.vmix_mode == RH_VMIX_GLS) RH_TRY(rh_gls_prestep(c, s, c->W, iic % 2, (iic + 1) % 2, iic, ntfirst));   // :352-357
     {
         TScope t(c, "halo");
         BcScope bcs(c);
@@ -171,6 +172,7 @@ static int advance_3d(rh_ctx *c, rh_state *s, int istep)
     RH_TRY(rh_update_massflux_3d(c, gbx2, 0, 1, s->yvel_new, s->vbar, s->Hvom, s->Hz, s->pm, s->DV_avg1, s->DV_avg2, s->mskv, N));   // :218
     RH_TRY(zero_outside(c, c->W, gbx1));                                                           // :230-231 (omega overwrites gbx1)
     RH_TRY(rh_omega(c, gbx1, c->W, s->Huon, s->Hvom, s->z_w, s->h, N));                            // :272-293
+    if (c->prm.vmix_mode == RH_VMIX_GLS) RH_TRY(rh_gls_corrector(c, s, c->W, istep % 2, 1 - istep % 2));   // :296-303
     if (!c->unfused) RH_TRY(launch_rhs_t3(c, s));                                                  // :341-346, 3 tracers in one sweep
     else for (int n = 0; n < RH_NCONS; n++)
         RH_TRY(rh_rhs_t_3d(c, bx, a4_comp(s->cons_new, n), a4_comp(s->sstore, n), s->Huon, s->Hvom, s->Hz, s->pn, s->pm, c->W, s->msku, s->mskv, N, dt));
@@ -336,7 +338,7 @@ __global__ void k_copy_comp2d(B3 b, A4 dst, A4 src)
     dst(i, j, 0) = src(i, j, 0);
 }
 
-static int setbox(rh_ctx *c, const rh_array4 &a, int comp, rh_box b, double v)
+int dev_setbox(rh_ctx *c, const rh_array4 &a, int comp, rh_box b, double v)
 {
     b = bx_and(b, bx_of(a)); if (!bx_ok(b)) return 0;
     k_setbox<<<grid3(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(a, comp), v);
@@ -365,6 +367,11 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
             &s->rufrc, &s->rvfrc, &s->sustr, &s->svstr, &s->rdrag, &s->bustr, &s->bvstr, &s->DU_avg1, &s->DU_avg2, &s->DV_avg1, &s->DV_avg2,
             &s->rubar, &s->rvbar, &s->rzeta, &s->zeta, &s->pm, &s->pn, &s->fcor, &s->sstore, &s->rhoS, &s->rhoA, &s->bvf};
         for (rh_array4 *a : all) RH_TRY(dev_setval(c, *a, 0, a->ncomp, 0.0));
+        if (P.vmix_mode == RH_VMIX_GLS)
+            for (rh_array4 *a : {&s->tke, &s->gls, &s->Lscale, &s->Akk, &s->Akp}) {
+                if (!a->p) return rh_fail("rh_init_state: vmix_mode = RH_VMIX_GLS needs the state's tke / gls / Lscale / Akk / Akp arrays");
+                RH_TRY(dev_setval(c, *a, 0, a->ncomp, 0.0));
+            }
     }
     for (rh_array4 *m : {&s->mskr, &s->msku, &s->mskv, &s->mskp}) RH_TRY(dev_setval(c, *m, 0, 1, 1.0));   // init_masks, make_new_level.cpp:381-389
     RH_TRY(dev_setval(c, s->rdrag, 0, 1, ip->rdrag));
@@ -388,8 +395,8 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
         RH_NEED(s->xvel_new, xb); RH_NEED(s->z_r, xb);
         k_init_u_log<<<grid3(xb), rh_block(), 0, c->stream>>>(mkB(xb), mkA(s->xvel_new), mkA(s->z_r), q);
         RH_LAUNCH_CHECK();
-    } else RH_TRY(setbox(c, s->xvel_new, 0, bx_nodal(bx, 0), ip->prob == 3 ? ip->u_0 : 0.0));
-    RH_TRY(setbox(c, s->yvel_new, 0, bx_nodal(bx, 1), (ip->prob == 3 || ip->prob == 4) ? ip->v_0 : 0.0));
+    } else RH_TRY(dev_setbox(c, s->xvel_new, 0, bx_nodal(bx, 0), ip->prob == 3 ? ip->u_0 : 0.0));
+    RH_TRY(dev_setbox(c, s->yvel_new, 0, bx_nodal(bx, 1), (ip->prob == 3 || ip->prob == 4) ? ip->v_0 : 0.0));
     RH_TRY(dev_setval(c, s->pm, 0, 1, dxi0)); RH_TRY(dev_setval(c, s->pn, 0, 1, dxi1));            // set_pm_pn
     {                                                                                              // set_2darrays
         const rh_box ub = bx_grow(bx_nodal(b2, 0), 2, 2, 0), vb = bx_grow(bx_nodal(b2, 1), 2, 2, 0), un = bx_union(ub, vb);
@@ -400,7 +407,7 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
         RH_TRY(halo_fillpatch(c, mfv(c, s->ubar, 1, 0, 0), s->msku, RH_BCV_UBAR, 0, 1));
         RH_TRY(halo_fillpatch(c, mfv(c, s->vbar, 0, 1, 0), s->mskv, RH_BCV_VBAR, 0, 1));
     }
-    RH_TRY(set_analytical_vmix(c, s));
+    if (P.vmix_mode == RH_VMIX_GLS) RH_TRY(launch_gls_init(c, s)); else RH_TRY(set_analytical_vmix(c, s));   // init_set_vmix, REMORA.cpp:550-562
     {                                                                                              // set_hmixcoef, REMORA.cpp:575-596
         double v = 0.0, d[RH_NCONS] = {0.0, 0.0, 0.0};
         if (ip->hmix_constant) { v = ip->visc2; for (int n = 0; n < RH_NCONS; n++) d[n] = ip->tnu2[n]; }

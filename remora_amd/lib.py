@@ -12,7 +12,7 @@ NCONS = 3
 NGROW = 2
 
 # BCVars / modes (include/remora_hip.h)
-VMIX_CONST, VMIX_UPWELLING = 0, 1
+VMIX_CONST, VMIX_UPWELLING, VMIX_GLS = 0, 1, 2
 SMFLUX_NONE, SMFLUX_UPWELLING, SMFLUX_FIXED = 0, 1, 2
 
 
@@ -42,6 +42,12 @@ def box(lo, hi):
     return b
 
 
+class GlsParams(C.Structure):
+    _fields_ = [("stability", C.c_int)] + [(k, C.c_double) for k in (
+        "gls_p", "gls_m", "gls_n", "gls_Kmin", "gls_Pmin", "gls_cmu0", "gls_c1", "gls_c2", "gls_c3m", "gls_c3p", "gls_sigk",
+        "gls_sigp", "Akk_bak", "Akp_bak", "Akv_bak", "Akt_bak", "Zos", "Zob")]
+
+
 class Params(C.Structure):
     _fields_ = [("domain_lo", C.c_int * 3), ("domain_hi", C.c_int * 3), ("periodic", C.c_int * 2),
                 ("box_lo", C.c_int * 3), ("box_hi", C.c_int * 3), ("nranks", C.c_int * 2), ("rank_xy", C.c_int * 2),
@@ -51,14 +57,15 @@ class Params(C.Structure):
                 ("g", C.c_double), ("rho0", C.c_double), ("R0", C.c_double), ("T0", C.c_double), ("S0", C.c_double),
                 ("Tcoef", C.c_double), ("Scoef", C.c_double), ("theta_s", C.c_double), ("theta_b", C.c_double),
                 ("tcline", C.c_double), ("vmix_mode", C.c_int), ("Akv_const", C.c_double), ("Akt_const", C.c_double * NCONS),
-                ("smflux_mode", C.c_int), ("masks_all_one", C.c_int)]
+                ("smflux_mode", C.c_int), ("masks_all_one", C.c_int), ("gls", GlsParams)]
 
 
 STATE_FIELDS = ["cons_old", "cons_new", "xvel_old", "xvel_new", "yvel_old", "yvel_new", "zvel_old", "zvel_new",
                 "Zt_avg1", "h", "ubar", "vbar", "ru", "rv", "ru2d", "rv2d", "mskr", "msku", "mskv", "mskp",
                 "z_w", "z_r", "Hz", "Huon", "Hvom", "Akv", "Akt", "visc2_p", "visc2_r", "diff2",
                 "rufrc", "rvfrc", "sustr", "svstr", "rdrag", "bustr", "bvstr", "DU_avg1", "DU_avg2", "DV_avg1", "DV_avg2",
-                "rubar", "rvbar", "rzeta", "zeta", "pm", "pn", "fcor", "sstore", "rhoS", "rhoA", "bvf"]
+                "rubar", "rvbar", "rzeta", "zeta", "pm", "pn", "fcor", "sstore", "rhoS", "rhoA", "bvf",
+                "tke", "gls", "Lscale", "Akk", "Akp"]
 
 
 class State(C.Structure):
@@ -117,6 +124,8 @@ SIGNATURES = {
     "rh_prestep_t": (C.c_int, [_P, Box] + [_A] * 11 + [C.c_int, C.c_int, C.c_int, C.c_double]),
     "rh_prestep_uv": (C.c_int, [_P, Box, C.c_int, C.c_int] + [_A] * 8 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
     "rh_t3dmix": (C.c_int, [_P, Box] + [_A] * 8 + [C.c_double, C.c_int]),
+    "rh_gls_prestep": (C.c_int, [_P, C.POINTER(State), _A, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rh_gls_corrector": (C.c_int, [_P, C.POINTER(State), _A, C.c_int, C.c_int]),
     "rh_coriolis": (C.c_int, [_P, Box, Box] + [_A] * 6 + [C.c_int, C.c_int]),
     "rh_rhs_uv_3d": (C.c_int, [_P, Box, Box] + [_A] * 17 + [C.c_int, C.c_int, C.c_int]),
     "rh_uv3dmix": (C.c_int, [_P, Box, Box] + [_A] * 12 + [C.c_int, C.c_int, C.c_double]),

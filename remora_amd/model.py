@@ -38,7 +38,17 @@ def make_params(case, box=None, nranks=(1, 1), rank_xy=(0, 0)):
         setattr(p, k, case[k])
     prob = case["prob"]
     # init_custom_vmix / init_custom_smflux of Exec/<case>/prob.cpp
-    if prob in ("Upwelling", "Advection", "DoublyPeriodic"):
+    if "gls" in case:                                        # remora.vertical_mixing_type = gls
+        from .cases import GLS_STAB
+        p.vmix_mode = L.VMIX_GLS
+        for k, v in case["gls"].items():
+            if k == "stab":
+                p.gls.stability = GLS_STAB[v]
+            elif k in ("p", "m", "n", "Kmin", "Pmin", "cmu0", "c1", "c2", "c3m", "c3p", "sigk", "sigp"):
+                setattr(p.gls, "gls_" + k, v)
+            else:
+                setattr(p.gls, k, v)
+    elif prob in ("Upwelling", "Advection", "DoublyPeriodic"):
         p.vmix_mode = L.VMIX_UPWELLING
     else:
         p.vmix_mode = L.VMIX_CONST

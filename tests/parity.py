@@ -12,6 +12,9 @@ COMPARE = ["cons_old", "cons_new", "xvel_old", "xvel_new", "yvel_old", "yvel_new
            "DU_avg1", "DU_avg2", "DV_avg1", "DV_avg2", "rubar", "rvbar", "rzeta", "zeta", "sstore", "rhoS", "rhoA", "bvf"]
 
 
+GLS_FIELDS = ["tke", "gls", "Lscale", "Akk", "Akp"]
+
+
 def _overlap(alo, ahi, blo, bhi):
     lo = [max(alo[d], blo[d]) for d in range(3)]
     hi = [min(ahi[d], bhi[d]) for d in range(3)]
@@ -27,6 +30,8 @@ def upload_oracle_state(orc, rem):
     """Copy every oracle field into the device state where the two arrays overlap and the oracle value is defined
     (the oracle NaN-fills fresh arrays, like the reference's fab.init_snan)."""
     for name in L.STATE_FIELDS:
+        if not getattr(rem.state, name).p:               # GLS arrays of a state bound without the closure
+            continue
         a, alo, ahi = orc.field(name)
         d, dlo, dhi = rem.get(name)
         lo, hi = _overlap(alo, ahi, dlo, dhi)

@@ -13,7 +13,7 @@ import pytest
 from remora_amd import cases
 from remora_amd.model import REMORA
 from oracle.oracle_py import Oracle
-from parity import upload_oracle_state, compare_states, worst
+from parity import upload_oracle_state, compare_states, worst, COMPARE, GLS_FIELDS
 from plotfile import read_plotfile, fcompare
 
 pytestmark = pytest.mark.gpu
@@ -54,6 +54,33 @@ def test_phases_against_oracle(case):
     rem.close(); orc.close()
 
 
+def test_gls_phases_against_oracle():
+    """vertical_mixing_type = gls (Upwelling_GLS): gls_prestep inside setup_step, gls_corrector inside advance_3d, compared with the
+    oracle after every phase over four steps (iic = 0, 1, 2, 3: both time-level parities and the first-step branch), ghost cells
+    included.  The closure calls pow() per point (device ocml vs glibc), so the bar is the north star's: 1e-12 of each field's
+    maximum per step on the turbulence fields and what they feed (Akv, Akt -> u, v, tracers)."""
+    case = "Upwelling_GLS"
+    cfg = cases.get(case)
+    orc = Oracle(cfg); rem = REMORA(cfg)
+    upload_oracle_state(orc, rem)
+    fields = COMPARE + GLS_FIELDS
+    for step in range(4):
+        orc.begin_step(); rem.begin_step()
+        orc.setup_step(); rem.setup_step()
+        res = compare_states(orc, rem, fields)
+        for iif in range(orc.nfast + 1):
+            orc.advance_2d_onestep(iif); rem.advance_2d_onestep(iif)
+        orc.advance_3d_ml(); rem.advance_3d_ml()
+        res2 = compare_states(orc, rem, fields)
+        orc.end_step(); rem.end_step()
+        for what, r in (("setup_step", res), ("advance_3d_ml", res2)):
+            name, err, rel = worst(r)
+            print(f"GLS step {step} {what}: worst {name} abs {err:.3e} rel {rel:.3e}")
+            bad = {k: v for k, v in r.items() if not (v[0] <= 1e-12 * (step + 1) * max(v[1], 1e-300) or v[0] <= 1e-18)}
+            assert not bad, f"{case} step {step} {what}: beyond 1e-12 per step: {bad}"
+    rem.close(); orc.close()
+
+
 @pytest.mark.parametrize("case", ["Seamount", "Advection"])
 def test_leaf_entry_points_against_oracle(case, monkeypatch):
     """RH_UNFUSED=1 makes the drivers go through the per-leaf C entry points (rh_prestep_t, rh_t3dmix, rh_rhs_t_3d, ...) instead
@@ -83,7 +110,7 @@ def test_mask_reading_path(case):
     rem.close(); orc.close()
 
 
-@pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection", "DoublyPeriodic", "DoublyPeriodic_bathy"])
+@pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection", "DoublyPeriodic", "DoublyPeriodic_bathy", "Upwelling_GLS"])
 def test_gold_plotfile(case):
     """Device-side initial state + ten steps through REMORA::Advance == the reference's regression test."""
     names, gold = read_plotfile(case)
