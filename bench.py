@@ -93,7 +93,7 @@ def bench_case(nx_per_gpu, ny_per_gpu, nz, px, py=None, name="DoubleGyre"):
     if py is None:
         px, py = 1, px
     c = cases.get(name)
-    if name == "Upwelling":            # dx = dy = 1 km as in the reference input (its bathymetry depends on the j index and on dx)
+    if name in ("Upwelling", "Upwelling_GLS"):   # dx = dy = 1 km as in the reference input (its bathymetry depends on the j index and on dx)
         c["prob_hi"] = (1000.0 * nx_per_gpu * px, 1000.0 * ny_per_gpu * py, 0.0)
         c["ncell"] = (nx_per_gpu * px, ny_per_gpu * py, nz)
         return c

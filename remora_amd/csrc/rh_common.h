@@ -160,6 +160,7 @@ struct rh_ctx {
     bool noregsolve = false;         // RH_NOREGSOLVE=1: the LDS-ring column solver instead of the register form (A/B parity and timing)
     bool nofuse2d = false;           // RH_NOFUSE2D=1: advance_2d as three kernels + the DUon/DVom exchange instead of k2d_fused (A/B parity)
     bool unfused = false;            // RH_UNFUSED=1: drivers call the per-leaf entry points instead of the fused kernels (A/B parity)
+    bool gls_libm_pow = false;       // RH_GLS_LIBM_POW=1: every per-point power of the GLS closure through pow() (A/B parity and timing)
     bool poison = false;             // RH_POISON=1: NaN-fill the work space at the start of every step (stale-read detector)
     ~rh_ctx() { if (bcq) bc_queue_delete(bcq); if (haloq) halo_queue_delete(haloq); }
 };

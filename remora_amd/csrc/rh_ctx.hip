@@ -300,6 +300,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     c->unfused = getenv("RH_UNFUSED") && atoi(getenv("RH_UNFUSED")) != 0;
     c->noregsolve = getenv("RH_NOREGSOLVE") && atoi(getenv("RH_NOREGSOLVE")) != 0;
     c->nofuse2d = getenv("RH_NOFUSE2D") && atoi(getenv("RH_NOFUSE2D")) != 0;
+    c->gls_libm_pow = getenv("RH_GLS_LIBM_POW") && atoi(getenv("RH_GLS_LIBM_POW")) != 0;
     c->poison = getenv("RH_POISON") && atoi(getenv("RH_POISON")) != 0;
 
     // stretching curves (here N = nz, DepthStretchTransform.H:49)

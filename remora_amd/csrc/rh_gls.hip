@@ -17,7 +17,36 @@ struct GlsC {
     double s0, s1, s2, s4, s5, s6, b0, b1, b2, b3, b4, b5, Sm2, Sm3, Sm4, Sh1, Sh2;
     double Zos_eff, Zob_min, Gadv, eps;
     double cmu0_p, surf_len_n, bot_len_n, Lsft_n;      // pow(cmu0,p), pow(L_sft*Zos_eff,n), pow(vonKar*Zob_min,n), pow(L_sft,n)
+    // exponent classes of the per-point powers (see gpow): m, n, -n, n-1, 1/n, -1/n, -m/n, 0.5+m/n, m+0.5n
+    int k_m, k_n, k_mn, k_nm1, k_e1, k_me1, k_mt1, k_t2, k_t4;
 };
+
+// The closure raises tke, gls and the length scale to exponents fixed by (gls_p, gls_m, gls_n).  For the named closures these are
+// multiples of 1/2 (k-epsilon: -1, -1.5, 1.5, -2, 1; k-omega: -1, -0.5, 0.5, ...), where a correctly rounded division / square
+// root / product chain is within one rounding or two of libm's pow() and ~20x cheaper than ocml's double pow (the column kernel
+// calls it ten times per point).  Any other exponent (the "gen" closure, n = -0.67) takes pow().
+enum { GP_POW = 0, GP_ZERO, GP_ONE, GP_MONE, GP_HALF, GP_MHALF, GP_1P5, GP_M1P5, GP_TWO, GP_MTWO };
+static int gpow_class(double e)
+{
+    if (e == 0.0) return GP_ZERO; if (e == 1.0) return GP_ONE; if (e == -1.0) return GP_MONE; if (e == 0.5) return GP_HALF;
+    if (e == -0.5) return GP_MHALF; if (e == 1.5) return GP_1P5; if (e == -1.5) return GP_M1P5; if (e == 2.0) return GP_TWO;
+    if (e == -2.0) return GP_MTWO; return GP_POW;
+}
+__device__ __forceinline__ double gpow(double x, double e, int cls)
+{
+    switch (cls) {
+    case GP_ZERO: return 1.0;
+    case GP_ONE: return x;
+    case GP_MONE: return 1.0 / x;
+    case GP_HALF: return sqrt(x);
+    case GP_MHALF: return 1.0 / sqrt(x);
+    case GP_1P5: return x * sqrt(x);
+    case GP_M1P5: return 1.0 / (x * sqrt(x));
+    case GP_TWO: return x * x;
+    case GP_MTWO: return 1.0 / (x * x);
+    default: return pow(x, e);
+    }
+}
 
 // REMORA_gls.cpp:230-349 (+ the defaults of REMORA_DataStruct.H:243-268,399-400,417,450-467), all on the host in double
 static GlsC gls_constants(const rh_ctx *c)
@@ -61,6 +90,10 @@ static GlsC gls_constants(const rh_ctx *c)
     const double Zos_min = std::max(G.Zos, 0.0001); q.Zob_min = std::max(G.Zob, 0.0001); q.Zos_eff = Zos_min;
     q.Gadv = 1.0 / 3.0; q.eps = 1.0e-10;
     q.cmu0_p = pow(cmu0, p); q.surf_len_n = pow(q.L_sft * q.Zos_eff, n); q.bot_len_n = pow(q.vonKar * q.Zob_min, n); q.Lsft_n = pow(q.L_sft, (n));
+    if (!c->gls_libm_pow) {
+        q.k_m = gpow_class(m); q.k_n = gpow_class(n); q.k_mn = gpow_class(-n); q.k_nm1 = gpow_class(n - 1.0); q.k_e1 = gpow_class(q.gls_exp1);
+        q.k_me1 = gpow_class(-q.gls_exp1); q.k_mt1 = gpow_class(-q.tke_exp1); q.k_t2 = gpow_class(q.tke_exp2); q.k_t4 = gpow_class(q.tke_exp4);
+    }
     return q;
 }
 
@@ -251,8 +284,8 @@ k_gls_column(B3 bx, A4 tke, A4 gls, A4 W, A4 Akv, A4 Akt, A4 Akk, A4 Akp, A4 Lsc
     const double tke_top = dmax_(g.cmu_fac3 * 0.5 * sqrt(su * su + sv * sv), g.Kmin);
     const double tke_bot = dmax_(g.cmu_fac3 * 0.5 * sqrt(bu * bu + bv * bv), g.Kmin);
     tke(i, j, N + 1, nnew) = tke_top; tke(i, j, 0, nnew) = tke_bot;
-    gls(i, j, N + 1, nnew) = dmax_(g.cmu0_p * pow(tke_top, g.gls_m) * g.surf_len_n, g.Pmin);
-    { const double cff_gls = g.fac4 * g.bot_len_n; gls(i, j, 0, nnew) = dmax_(cff_gls * pow(tke_bot, (g.gls_m)), g.Pmin); }
+    gls(i, j, N + 1, nnew) = dmax_(g.cmu0_p * gpow(tke_top, g.gls_m, g.k_m) * g.surf_len_n, g.Pmin);
+    { const double cff_gls = g.fac4 * g.bot_len_n; gls(i, j, 0, nnew) = dmax_(cff_gls * gpow(tke_bot, (g.gls_m), g.k_m), g.Pmin); }
 
     // ---- sweep A (k = N..1)
     auto diffc = [&](const A4 &Ak, int k) { return (k == 0 || k == N) ? 0.0 : cffd * (Ak(i, j, k) + Ak(i, j, k + 1)) / Hz(i, j, k); };
@@ -285,7 +318,7 @@ k_gls_column(B3 bx, A4 tke, A4 gls, A4 W, A4 Akv, A4 Akt, A4 Akk, A4 Akp, A4 Lsc
                        0.25 / (g.vonKar * g.vonKar) *
                        pow(pow(gn, g.gls_exp1) * g.cmu_fac1 * pow(tn, -g.tke_exp1) * (1.0 / (z_w(i, j, N + 1) - z_w(i, j, k))), 2.0);
         }
-        const double diss_g = pow(gn, (-g.gls_exp1)), diss_t = pow(tn, g.tke_exp2);
+        const double diss_g = gpow(gn, (-g.gls_exp1), g.k_me1), diss_t = gpow(tn, g.tke_exp2, g.k_t2);
         const double BCK = cff_Hz * (1.0 + dt * diss_g * g.cmu_fac2 * diss_t + dt * (1.0 - on1) * strat2 * (akt - g.Akt_bak) / tn) - fdK - fdK_m;
         const double BCP = cff_Hz * (1.0 + dt * g.c2 * wall_fac * diss_g * g.cmu_fac2 * diss_t + dt * (1.0 - on2) * c3 * strat2 * (akt - g.Akt_bak) / tn) - fdP - fdP_m;
         // forward elimination for tke (:749-758), tke_fluxt = 0
@@ -309,9 +342,9 @@ k_gls_column(B3 bx, A4 tke, A4 gls, A4 W, A4 Akv, A4 Akt, A4 Akk, A4 Akp, A4 Lsc
     const double tkeN = t_lo;
     // ---- surface and bottom flux of gls (:767-775)
     double ct = 0.5 * (tke_top + tkeN);
-    const double gls_fluxt = dt * g.fac3 * pow(ct, g.gls_m) * g.Lsft_n * pow(g.Zos_eff + 0.5 * Hz(i, j, N), g.gls_n - 1.0) * 0.5 * (Akp(i, j, N + 1) + Akp(i, j, N));
+    const double gls_fluxt = dt * g.fac3 * gpow(ct, g.gls_m, g.k_m) * g.Lsft_n * gpow(g.Zos_eff + 0.5 * Hz(i, j, N), g.gls_n - 1.0, g.k_nm1) * 0.5 * (Akp(i, j, N + 1) + Akp(i, j, N));
     ct = 0.5 * (tke_bot + tke1);
-    const double gls_fluxb = dt * g.fac2 * pow(ct, g.gls_m) * pow(0.5 * Hz(i, j, 0) + g.Zob_min, g.gls_n - 1.0) * 0.5 * (Akp(i, j, 0) + Akp(i, j, 1));
+    const double gls_fluxb = dt * g.fac2 * gpow(ct, g.gls_m, g.k_m) * gpow(0.5 * Hz(i, j, 0) + g.Zob_min, g.gls_n - 1.0, g.k_nm1) * 0.5 * (Akp(i, j, 0) + Akp(i, j, 1));
     // ---- sweep C: forward elimination for gls (:776-783)
     fdP = diffc(Akp, N);
     double p_up = 0.0, cp = 0.0; cf_up = 0.0;
@@ -333,13 +366,13 @@ k_gls_column(B3 bx, A4 tke, A4 gls, A4 W, A4 Akv, A4 Akt, A4 Akk, A4 Akp, A4 Lsc
         double t = dmax_(tke(i, j, k, nnew), g.Kmin);
         double p = dmax_(p_solved, g.Pmin);
         const double buoy2 = B2(i, j, k), shear2 = S2(i, j, k);
-        if (g.gls_n >= 0.0) p = dmin_(p, g.fac5 * pow(t, g.tke_exp4) * pow(sqrt(dmax_(0.0, buoy2)) + g.eps, -g.gls_n));
-        else p = dmax_(p, g.fac5 * pow(t, (g.tke_exp4)) * pow((sqrt(dmax_(0.0, buoy2)) + g.eps), (-g.gls_n)));
+        if (g.gls_n >= 0.0) p = dmin_(p, g.fac5 * gpow(t, g.tke_exp4, g.k_t4) * gpow(sqrt(dmax_(0.0, buoy2)) + g.eps, -g.gls_n, g.k_mn));
+        else p = dmax_(p, g.fac5 * gpow(t, (g.tke_exp4), g.k_t4) * gpow((sqrt(dmax_(0.0, buoy2)) + g.eps), (-g.gls_n), g.k_mn));
         double Ls_lmt;
-        const double Ls_unlmt = dmax_(g.eps, pow(p, (g.gls_exp1)) * g.cmu_fac1 * pow(t, (-g.tke_exp1)));
+        const double Ls_unlmt = dmax_(g.eps, gpow(p, (g.gls_exp1), g.k_e1) * g.cmu_fac1 * gpow(t, (-g.tke_exp1), g.k_mt1));
         if (buoy2 > 0.0) Ls_lmt = dmin_(Ls_unlmt, sqrt(0.56 * t / (dmax_(0.0, buoy2) + g.eps)));
         else Ls_lmt = Ls_unlmt;
-        p = dmax_(g.cmu0_p * pow(t, g.gls_m) * pow(Ls_lmt, g.gls_n), g.Pmin);
+        p = dmax_(g.cmu0_p * gpow(t, g.gls_m, g.k_m) * gpow(Ls_lmt, g.gls_n, g.k_n), g.Pmin);
         double Sh, Sm;
         double Gh = dmin_(g.Gh0, -buoy2 * Ls_lmt * Ls_lmt / (2.0 * t));
         Gh = dmin_(Gh, Gh - (Gh - g.Ghcri) * (Gh - g.Ghcri) / (Gh + g.Gh0 - 2.0 * g.Ghcri));

@@ -58,7 +58,8 @@ def main():
         r.sync()
     run(rem)
     mine = {}
-    for f in FIELDS:
+    fields = FIELDS + (["tke", "gls", "Lscale", "Akk", "Akp", "Akt"] if "gls" in cfg else [])
+    for f in fields:
         a, lo, hi = rem.get(f)
         mine[f] = (a, lo, hi)
     gathered = [None] * world
@@ -67,7 +68,7 @@ def main():
     if rank == 0:
         ref = REMORA(cfg, device="cuda:0")
         run(ref)
-        for f in FIELDS:
+        for f in fields:
             g, glo, ghi = ref.get(f)
             gng1 = -glo[1]
             nod_j = (ghi[1] - glo[1] + 1) - 2 * gng1 - ny

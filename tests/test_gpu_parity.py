@@ -54,11 +54,15 @@ def test_phases_against_oracle(case):
     rem.close(); orc.close()
 
 
-def test_gls_phases_against_oracle():
-    """vertical_mixing_type = gls (Upwelling_GLS): gls_prestep inside setup_step, gls_corrector inside advance_3d, compared with the
+@pytest.mark.parametrize("libm_pow", [0, 1])
+def test_gls_phases_against_oracle(libm_pow, monkeypatch):
+    """libm_pow = 1: every per-point power through the device pow(); 0 (the default build): half-integer exponents through
+    division / sqrt chains (rh_gls.hip: gpow).  Both must meet the same bar.
+    vertical_mixing_type = gls (Upwelling_GLS): gls_prestep inside setup_step, gls_corrector inside advance_3d, compared with the
     oracle after every phase over four steps (iic = 0, 1, 2, 3: both time-level parities and the first-step branch), ghost cells
     included.  The closure calls pow() per point (device ocml vs glibc), so the bar is the north star's: 1e-12 of each field's
     maximum per step on the turbulence fields and what they feed (Akv, Akt -> u, v, tracers)."""
+    monkeypatch.setenv("RH_GLS_LIBM_POW", str(libm_pow))
     case = "Upwelling_GLS"
     cfg = cases.get(case)
     orc = Oracle(cfg); rem = REMORA(cfg)
