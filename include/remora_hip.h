@@ -46,7 +46,8 @@ typedef struct rh_gls_params {
     double Akk_bak, Akp_bak, Akv_bak, Akt_bak, Zos, Zob;
 } rh_gls_params;
 /* analytic surface momentum flux = init_custom_smflux hooks called by set_smflux (Source/REMORA.cpp:598-605) */
-enum { RH_SMFLUX_NONE = 0, RH_SMFLUX_UPWELLING = 1, RH_SMFLUX_FIXED = 2 };
+enum { RH_SMFLUX_NONE = 0, RH_SMFLUX_UPWELLING = 1, RH_SMFLUX_FIXED = 2,
+       RH_SMFLUX_CHANNEL = 3 };   /* Exec/Channel_Test/prob.cpp:204-222: uniform along-channel wind oscillating at 0.9 f */
 
 /* Hidden inputs of the reference's member functions: geom[0] (domain, periodicity), solverChoice
  * (Source/REMORA_DataStruct.H:351-483), fixed_ndtfast_ratio, and the process grid of this rank. */
@@ -236,7 +237,7 @@ int  rh_est_timestep(rh_ctx *ctx, rh_state *s, double cfl, int local_only, doubl
 int  rh_sum_integrated_quantities(rh_ctx *ctx, rh_state *s, int local_only, double out4[4]);
 
 /* ---- synthetic initial state (outside the hot path; what InitData / prob.cpp provide in REMORA) ---- */
-/* Fills a bound native state for one of the pinned problems (0 Upwelling, 1 Seamount, 2 DoubleGyre, 3 Advection, 4 DoublyPeriodic):
+/* Fills a bound native state for one of the pinned problems (0 Upwelling, 1 Seamount, 2 DoubleGyre, 3 Advection, 4 DoublyPeriodic, 5 Channel_Test):
  * Source/REMORA.cpp:246-342,608-702, Initialization/REMORA_init.cpp, Exec/<case>/prob.cpp.  Synchronises. */
 typedef struct rh_init_params {
     int prob; double rdrag, coriolis_f0, coriolis_beta; int hmix_constant; double visc2, tnu2[RH_NCONS]; double u_0, v_0;

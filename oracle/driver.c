@@ -108,6 +108,7 @@ static void init_bathymetry(OState *s)
         } else FORBOX2D(g3,i,j){ VN(h,i,j,0,0)=-P->prob_lo[2]; VN(h,i,j,0,1)=VN(h,i,j,0,0); }
     } break;
     case CASE_DOUBLEGYRE: fab_setval(h,500.0); break;                          /* Exec/DoubleGyre/prob.cpp:21-28 */
+    case CASE_CHANNEL: fab_setval(h,50.0); break;                              /* Exec/Channel_Test/prob.cpp:20-52 */
     case CASE_DOUBLYPERIODIC: {                                                /* Exec/DoublyPeriodic/prob.cpp:32-105 */
         fab_setval(h,P->prob_hi[2]);
         int Lm=s->nx, Mm=s->ny;
@@ -174,6 +175,14 @@ static void init_prob(OState *s)
             VN(st,i,j,k,2)=(r2<radsq)?1.0:0.0;
         }
         break;
+    case CASE_CHANNEL:                                                         /* Exec/Channel_Test/prob.cpp:73-150 */
+        FORBOX(s->bx,i,j,k){
+            double z=V(z_r,i,j,k), y=P->prob_lo[1]+(j+0.5)*dx1;
+            VN(st,i,j,k,0)=T0+z/(9.8*1.7);
+            if(P->use_salt) VN(st,i,j,k,1)=S0+y/(9.8*760.0);
+            VN(st,i,j,k,2)=0.0;
+        }
+        break;
     case CASE_ADVECTION:                                                       /* Exec/Advection/prob.cpp:72-157 */
         FORBOX(s->bx,i,j,k){
             VN(st,i,j,k,0)=T0;
@@ -190,6 +199,14 @@ static void init_prob(OState *s)
         Box b=s->xvel_new.valid; Fab f=F(xvel_new);
         FORBOX(b,i,j,k){ double z=-V(z_r,i,j,k);
             V(f,i,j,k)=P->u_0+P->uRef*log((z+P->z0)/P->z0)/log((P->zRef+P->z0)/P->z0); }
+    } else if(P->prob==CASE_CHANNEL){                                          /* Exec/Channel_Test/prob.cpp:126-141: sheared, wavy along-channel flow */
+        Box b=s->xvel_new.valid; Fab f=F(xvel_new);
+        FORBOX(b,i,j,k){
+            double z=V(z_r,i,j,k), depth=50.0;
+            double x=P->prob_lo[0]+(i+0.5)*dx0, y=P->prob_lo[1]+(j+0.5)*dx1;
+            double val1=x*6.28318530718*1.0e-5, val2=y*6.28318530718*1.0e-5;
+            V(f,i,j,k)=(depth+z)*0.01+0.05*sin(val1)*sin(val2);
+        }
     } else
     { Box b=s->xvel_new.valid; Fab f=F(xvel_new); FORBOX(b,i,j,k) V(f,i,j,k)=u0; }
     { Box b=s->yvel_new.valid; Fab f=F(yvel_new); FORBOX(b,i,j,k) V(f,i,j,k)=v0; }
@@ -202,7 +219,7 @@ static void init_vmix(OState *s)
     Box b=box_grow(s->Akv.valid,NGROW,NGROW,0);
     FORBOX(b,i,j,k){
         switch(P->prob){
-        case CASE_UPWELLING: case CASE_ADVECTION: case CASE_DOUBLYPERIODIC:    /* Exec/Upwelling/prob.cpp:163-185, DoublyPeriodic/prob.cpp:222-244 */
+        case CASE_UPWELLING: case CASE_ADVECTION: case CASE_DOUBLYPERIODIC: case CASE_CHANNEL:   /* Exec/Upwelling/prob.cpp:163-185, DoublyPeriodic/prob.cpp:222-244, Channel_Test/prob.cpp:152-176 */
             V(Akv,i,j,k)=2.0e-03+8.0e-03*exp(V(z_w,i,j,k)/150.0);
             VN(Akt,i,j,k,0)=1.0e-6; VN(Akt,i,j,k,1)=1.0e-6; VN(Akt,i,j,k,2)=0.0; break;
         case CASE_SEAMOUNT:                                                    /* Exec/Seamount/prob.cpp:167-190 */
@@ -245,7 +262,8 @@ static void init_hmix(OState *s)
         Box b=box_grow(s->bx,NGROW,NGROW,0);
         double v=0.0,d=0.0;
         switch(P->prob){ case CASE_UPWELLING: case CASE_ADVECTION: case CASE_DOUBLYPERIODIC: v=5.0; d=0.0; break;
-                         case CASE_SEAMOUNT: v=0.0; d=0.0; break; case CASE_DOUBLEGYRE: v=1280.0; d=1280.0; break; }
+                         case CASE_SEAMOUNT: v=0.0; d=0.0; break; case CASE_DOUBLEGYRE: v=1280.0; d=1280.0; break;
+                         case CASE_CHANNEL: v=2.0; d=0.0; break; }                 /* Exec/Channel_Test/prob.cpp:178-202 */
         FORBOX(b,i,j,k){ V(vp,i,j,k)=v; V(vr,i,j,k)=v; for(int n=0;n<NCONS;n++) VN(d2,i,j,k,n)=d; }
     }
     o_fillpatch(&s->geom,&s->visc2_p,F(mskr),BCV_FOEXTRAP_PERIODIC,0,1);        /* Source/REMORA.cpp:591-595 */
@@ -272,6 +290,11 @@ static void init_smflux(OState *s,double time)
         } else if(P->periodic[0]) fab_setval(sv,0.0);
     } break;
     case CASE_SEAMOUNT: case CASE_ADVECTION: fab_setval(su,0.0); fab_setval(sv,0.0); break;
+    case CASE_CHANNEL: {                                                       /* Exec/Channel_Test/prob.cpp:204-222: oscillating along-channel wind */
+        double tdays=time/(24.0*60.0*60.0), dstart=0.0, userval=0.01, fcor=1.0e-4;
+        double windamp_u=userval*sin(0.9*fcor*86400.0*(tdays-dstart))/P->rho0;
+        fab_setval(su,windamp_u); fab_setval(sv,0.0);
+    } break;
     case CASE_DOUBLEGYRE: {                                                    /* Exec/DoubleGyre/prob.cpp:167-206 */
         double pi=3.14159265359;
         double yextent=P->prob_hi[1]-P->prob_lo[1];

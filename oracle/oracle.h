@@ -24,7 +24,7 @@ enum { BCV_CONS=0, BCV_TEMP=0, BCV_SALT, BCV_SCALAR, BCV_XVEL=NCONS, BCV_YVEL, B
 
 typedef struct { int lo[3], hi[3]; } BCRec;
 
-enum { CASE_UPWELLING=0, CASE_SEAMOUNT=1, CASE_DOUBLEGYRE=2, CASE_ADVECTION=3, CASE_DOUBLYPERIODIC=4 };
+enum { CASE_UPWELLING=0, CASE_SEAMOUNT=1, CASE_DOUBLEGYRE=2, CASE_ADVECTION=3, CASE_DOUBLYPERIODIC=4, CASE_CHANNEL=5 };
 
 /* vertical_mixing_type = gls: SolverChoice's GLS block, Source/REMORA_DataStruct.H:203-268,399-400,427-445
  * stab: 0 Canuto_A, 1 Canuto_B, 2 Galperin */

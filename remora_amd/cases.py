@@ -7,7 +7,7 @@ the SolverChoice defaults of Source/REMORA_DataStruct.H:351-483 it leaves untouc
 import copy
 
 GLS_STAB = {"Canuto_A": 0, "Canuto_B": 1, "Galperin": 2}
-PROB = {"Upwelling": 0, "Seamount": 1, "DoubleGyre": 2, "Advection": 3, "DoublyPeriodic": 4}
+PROB = {"Upwelling": 0, "Seamount": 1, "DoubleGyre": 2, "Advection": 3, "DoublyPeriodic": 4, "Channel_Test": 5}
 
 _DEFAULTS = dict(
     flat_bathymetry=1, tracer_c4=0, uv_c2=0, use_coriolis=0, use_prestep=1, use_uv3dmix=1,
@@ -48,6 +48,15 @@ CASES["DoublyPeriodic_bathy"] = dict(CASES["DoublyPeriodic"], flat_bathymetry=0)
 CASES["Upwelling_GLS"] = dict(CASES["Upwelling"], gls=dict(
     stab="Galperin", p=3.0, m=1.5, n=-1.0, Kmin=7.6e-6, Pmin=1.0e-12, cmu0=0.5477, c1=1.44, c2=1.92, c3m=-0.4, c3p=1.0,
     sigk=1.0, sigp=1.3, Akk_bak=5.0e-6, Akp_bak=5.0e-6, Akv_bak=1.0e-5, Akt_bak=1.0e-6, Zos=2e-2, Zob=2e-2))
+
+# Tests/test_files/Channel_Test/Channel_Test.i (Exec/Channel_Test): x-periodic channel, 50 levels, salinity-dependent density,
+# oscillating wind, GLS with the default stability type (Canuto_A, REMORA_DataStruct.H:206) and Zos = Zob = 2 mm
+CASES["Channel_Test"] = dict(_DEFAULTS, prob="Channel_Test", ncell=(20, 60, 50), prob_lo=(0., 0., -50.), prob_hi=(100000., 300000., 0.),
+                             periodic=(1, 0), fixed_dt=400.0, ndtfast=10, flat_bathymetry=0, R0=1027.0, S0=15.0, T0=10.0,
+                             Tcoef=1.7e-4, Scoef=7.6e-4, rho0=1025.0, tcline=25.0, use_coriolis=1, coriolis_f0=1.0e-4, coriolis_beta=0.0,
+                             gls=dict(stab="Canuto_A", p=3.0, m=1.5, n=-1.0, Kmin=7.6e-6, Pmin=1.0e-12, cmu0=0.5477, c1=1.44, c2=1.92,
+                                      c3m=-0.4, c3p=1.0, sigk=1.0, sigp=1.3, Akk_bak=5.0e-6, Akp_bak=5.0e-6, Akv_bak=1.0e-5,
+                                      Akt_bak=1.0e-6, Zos=0.002, Zob=0.002))
 
 
 def get(name):

@@ -9,6 +9,11 @@ static int set_smflux(rh_ctx *c, rh_state *s, double time)
     const rh_params &P = c->prm;
     if (P.smflux_mode == RH_SMFLUX_FIXED) return 0;
     if (P.smflux_mode == RH_SMFLUX_NONE) { RH_TRY(dev_setval(c, s->sustr, 0, 1, 0.0)); return dev_setval(c, s->svstr, 0, 1, 0.0); }
+    if (P.smflux_mode == RH_SMFLUX_CHANNEL) {                                   // Exec/Channel_Test/prob.cpp:204-222
+        const double tdays = time / (24.0 * 60.0 * 60.0), dstart = 0.0, userval = 0.01, fcor = 1.0e-4;
+        const double windamp_u = userval * sin(0.9 * fcor * 86400.0 * (tdays - dstart)) / P.rho0;
+        RH_TRY(dev_setval(c, s->sustr, 0, 1, windamp_u)); return dev_setval(c, s->svstr, 0, 1, 0.0);
+    }
     if (P.smflux_mode != RH_SMFLUX_UPWELLING) return rh_fail("set_smflux: unknown smflux_mode %d", P.smflux_mode);
     const double pi = 3.14159265359, tdays = time / (24.0 * 60.0 * 60.0), dstart = 0.0;
     double windamp;
@@ -275,6 +280,11 @@ __global__ void k_init_cons(B3 b, A4 st, A4 z_r, InitPar q)
         st(i, j, k, 0) = val3 - 3.0 * val4;
         if (q.use_salt) st(i, j, k, 1) = 34.5 - 0.001 * z - val4;
         st(i, j, k, 2) = 0.0;
+    } else if (q.prob == 5) {                                                  // Channel_Test/prob.cpp:73-110
+        const double y = q.plo[1] + (j + 0.5) * q.dx1;
+        st(i, j, k, 0) = q.T0 + z / (9.8 * 1.7);
+        if (q.use_salt) st(i, j, k, 1) = q.S0 + y / (9.8 * 760.0);
+        st(i, j, k, 2) = 0.0;
     } else if (q.prob == 4) {                                                  // DoublyPeriodic/prob.cpp:126-180
         st(i, j, k, 0) = q.T0 + 8.0 * exp(z / 50.0);
         if (q.use_salt) st(i, j, k, 1) = q.S0;
@@ -298,6 +308,16 @@ __global__ void k_init_u_log(B3 b, A4 u, A4 z_r, InitPar q)
     const int k = b.lo2 + RH_KZ;
     const double z = -z_r(i, j, k);
     u(i, j, k) = q.u0 + q.uRef * log((z + q.z0) / q.z0) / log((q.zRef + q.z0) / q.z0);
+}
+// sheared, wavy along-channel flow of Exec/Channel_Test/prob.cpp:126-141 (x, y at the cell centre of index (i, j), as the reference has it)
+__global__ void k_init_u_channel(B3 b, A4 u, A4 z_r, InitPar q)
+{
+    RH_IJ(b); if (!inb2(b, i, j)) return;
+    const int k = b.lo2 + RH_KZ;
+    const double z = z_r(i, j, k), depth = 50.0;
+    const double x = q.plo[0] + (i + 0.5) * q.dx0, y = q.plo[1] + (j + 0.5) * q.dx1;
+    const double val1 = x * 6.28318530718 * 1.0e-5, val2 = y * 6.28318530718 * 1.0e-5;
+    u(i, j, k) = (depth + z) * 0.01 + 0.05 * sin(val1) * sin(val2);
 }
 __global__ void k_setbox(B3 b, A4 a, double v)
 {
@@ -350,7 +370,7 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
     const rh_params &P = c->prm;
     const int N = c->N;
     const rh_box bx = c->bx, b2 = bx_slab(bx, 2, 0);
-    if (ip->prob < 0 || ip->prob > 4) return rh_fail("rh_init_state: unknown problem %d", ip->prob);
+    if (ip->prob < 0 || ip->prob > 5) return rh_fail("rh_init_state: unknown problem %d", ip->prob);
     InitPar q; memset(&q, 0, sizeof q);
     q.prob = ip->prob; q.nx = c->dom.hi[0] - c->dom.lo[0] + 1; q.ny = c->dom.hi[1] - c->dom.lo[1] + 1;
     q.perx = P.periodic[0]; q.pery = P.periodic[1]; q.flat = P.flat_bathymetry; q.use_salt = P.use_salt;
@@ -377,6 +397,7 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
     RH_TRY(dev_setval(c, s->rdrag, 0, 1, ip->rdrag));
     // bathymetry (set_bathymetry, REMORA.cpp:464-526)
     if (ip->prob == 2) RH_TRY(dev_setval(c, s->h, 0, 2, 500.0));                                   // DoubleGyre/prob.cpp:21-28
+    else if (ip->prob == 5) RH_TRY(dev_setval(c, s->h, 0, 2, 50.0));                               // Channel_Test/prob.cpp:20-52
     else {
         RH_TRY(dev_setval(c, s->h, 0, 2, P.prob_hi[2]));
         rh_box hb = (ip->prob == 0 || ip->prob == 4) ? bx_grow(b2, 2, 2, 0) : (ip->prob == 1 ? bx_grow(b2, 3, 3, 0) : bx_of(s->h));
@@ -390,10 +411,11 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
     // init_custom_prob
     k_init_cons<<<grid3(bx), rh_block(), 0, c->stream>>>(mkB(bx), mkA(s->cons_new), mkA(s->z_r), q);
     RH_LAUNCH_CHECK();
-    if (ip->prob == 4) {
+    if (ip->prob == 4 || ip->prob == 5) {
         const rh_box xb = bx_nodal(bx, 0);
         RH_NEED(s->xvel_new, xb); RH_NEED(s->z_r, xb);
-        k_init_u_log<<<grid3(xb), rh_block(), 0, c->stream>>>(mkB(xb), mkA(s->xvel_new), mkA(s->z_r), q);
+        if (ip->prob == 4) k_init_u_log<<<grid3(xb), rh_block(), 0, c->stream>>>(mkB(xb), mkA(s->xvel_new), mkA(s->z_r), q);
+        else k_init_u_channel<<<grid3(xb), rh_block(), 0, c->stream>>>(mkB(xb), mkA(s->xvel_new), mkA(s->z_r), q);
         RH_LAUNCH_CHECK();
     } else RH_TRY(dev_setbox(c, s->xvel_new, 0, bx_nodal(bx, 0), ip->prob == 3 ? ip->u_0 : 0.0));
     RH_TRY(dev_setbox(c, s->yvel_new, 0, bx_nodal(bx, 1), (ip->prob == 3 || ip->prob == 4) ? ip->v_0 : 0.0));
@@ -412,6 +434,7 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
         double v = 0.0, d[RH_NCONS] = {0.0, 0.0, 0.0};
         if (ip->hmix_constant) { v = ip->visc2; for (int n = 0; n < RH_NCONS; n++) d[n] = ip->tnu2[n]; }
         else if (ip->prob == 0 || ip->prob == 3 || ip->prob == 4) v = 5.0;
+        else if (ip->prob == 5) v = 2.0;                                                           // Channel_Test/prob.cpp:178-202
         else if (ip->prob == 2) { v = 1280.0; for (int n = 0; n < RH_NCONS; n++) d[n] = 1280.0; }
         RH_TRY(dev_setval(c, s->visc2_p, 0, 1, v)); RH_TRY(dev_setval(c, s->visc2_r, 0, 1, v));
         for (int n = 0; n < RH_NCONS; n++) RH_TRY(dev_setval(c, s->diff2, n, 1, d[n]));

@@ -13,7 +13,7 @@ NGROW = 2
 
 # BCVars / modes (include/remora_hip.h)
 VMIX_CONST, VMIX_UPWELLING, VMIX_GLS = 0, 1, 2
-SMFLUX_NONE, SMFLUX_UPWELLING, SMFLUX_FIXED = 0, 1, 2
+SMFLUX_NONE, SMFLUX_UPWELLING, SMFLUX_FIXED, SMFLUX_CHANNEL = 0, 1, 2, 3
 
 
 class Array4(C.Structure):

@@ -58,7 +58,7 @@ def make_params(case, box=None, nranks=(1, 1), rank_xy=(0, 0)):
         p.Akt_const[1] = akt
         p.Akt_const[2] = 0.0
     p.smflux_mode = {"Upwelling": L.SMFLUX_UPWELLING, "Seamount": L.SMFLUX_NONE, "Advection": L.SMFLUX_NONE,
-                     "DoubleGyre": L.SMFLUX_FIXED, "DoublyPeriodic": L.SMFLUX_UPWELLING}[prob]
+                     "DoubleGyre": L.SMFLUX_FIXED, "DoublyPeriodic": L.SMFLUX_UPWELLING, "Channel_Test": L.SMFLUX_CHANNEL}[prob]
     p.masks_all_one = int(case.get("masks_all_one", 1))      # every pinned case has mask == 1 (make_new_level.cpp:381-389)
     return p
 

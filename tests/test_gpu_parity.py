@@ -54,16 +54,16 @@ def test_phases_against_oracle(case):
     rem.close(); orc.close()
 
 
-@pytest.mark.parametrize("libm_pow", [0, 1])
-def test_gls_phases_against_oracle(libm_pow, monkeypatch):
-    """libm_pow = 1: every per-point power through the device pow(); 0 (the default build): half-integer exponents through
+@pytest.mark.parametrize("case,libm_pow", [("Upwelling_GLS", 0), ("Upwelling_GLS", 1), ("Channel_Test", 0)])
+def test_gls_phases_against_oracle(case, libm_pow, monkeypatch):
+    """Upwelling_GLS: Galperin stability functions, 16 levels; Channel_Test: Canuto_A, 50 levels, salinity-dependent density.
+    libm_pow = 1: every per-point power through the device pow(); 0 (the default build): half-integer exponents through
     division / sqrt chains (rh_gls.hip: gpow).  Both must meet the same bar.
     vertical_mixing_type = gls (Upwelling_GLS): gls_prestep inside setup_step, gls_corrector inside advance_3d, compared with the
     oracle after every phase over four steps (iic = 0, 1, 2, 3: both time-level parities and the first-step branch), ghost cells
     included.  The closure calls pow() per point (device ocml vs glibc), so the bar is the north star's: 1e-12 of each field's
     maximum per step on the turbulence fields and what they feed (Akv, Akt -> u, v, tracers)."""
     monkeypatch.setenv("RH_GLS_LIBM_POW", str(libm_pow))
-    case = "Upwelling_GLS"
     cfg = cases.get(case)
     orc = Oracle(cfg); rem = REMORA(cfg)
     upload_oracle_state(orc, rem)
@@ -114,7 +114,7 @@ def test_mask_reading_path(case):
     rem.close(); orc.close()
 
 
-@pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection", "DoublyPeriodic", "DoublyPeriodic_bathy", "Upwelling_GLS"])
+@pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection", "DoublyPeriodic", "DoublyPeriodic_bathy", "Upwelling_GLS", "Channel_Test"])
 def test_gold_plotfile(case):
     """Device-side initial state + ten steps through REMORA::Advance == the reference's regression test."""
     names, gold = read_plotfile(case)

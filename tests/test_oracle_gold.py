@@ -13,7 +13,7 @@ from oracle.oracle_py import Oracle, set_weights
 from plotfile import read_plotfile, fcompare
 
 
-@pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection", "DoublyPeriodic", "DoublyPeriodic_bathy", "Upwelling_GLS"])
+@pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection", "DoublyPeriodic", "DoublyPeriodic_bathy", "Upwelling_GLS", "Channel_Test"])
 def test_oracle_reproduces_gold_plotfile(case):
     names, gold = read_plotfile(case)
     orc = Oracle(cases.get(case))
@@ -25,7 +25,7 @@ def test_oracle_reproduces_gold_plotfile(case):
     assert all(r[2] for r in res), f"{case}: {list(zip(names, res))}"
 
 
-@pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection", "DoublyPeriodic", "DoublyPeriodic_bathy", "Upwelling_GLS"])
+@pytest.mark.parametrize("case", ["Upwelling", "Seamount", "DoubleGyre", "Advection", "DoublyPeriodic", "DoublyPeriodic_bathy", "Upwelling_GLS", "Channel_Test"])
 def test_gold_cell_h_minmax(case):
     """The per-box min/max of every component recorded in the gold Cell_H must match what the FAB reader returns: pins the
     reader (byte order, component order, multi-box assembly for Advection's 9 boxes)."""
