@@ -336,7 +336,7 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
     constexpr int NT = RT_BX * U_BY;
     __shared__ double lds[QF_N * NT];
     static_assert(T_N * F_N <= QF_N * NT, "tiles alias the flux slots");
-    static_assert(F_N <= 2 * NT, "two tile points per thread");
+    constexpr int TR = (F_N + NT - 1) / NT;                  // tile points per thread
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
     const RhTile rh_t_ = rh_tile();
     const int I0 = un.lo0 - 1 + rh_t_.x * U_SX, J0 = un.lo1 - 1 + rh_t_.y * U_SY;
@@ -345,10 +345,10 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
     const bool owner = in_rb && (tx >= 1 || rh_t_.x == 0) && (ty >= 1 || rh_t_.y == 0);
     const bool is_u = tx >= 1 && ty <= U_BY - 2 && inb2(xb, i, j), is_v = tx <= RT_BX - 2 && ty >= 1 && inb2(yb, i, j);
 
-    // ---- (1) all global loads.  Tile points first: t = tid and tid + NT
-    double tz[2], th[2], tpm[2], tpn[2], tub[2], tvb[2], tdu[2], tdv[2];
+    // ---- (1) all global loads.  Tile points first: t = tid, tid + NT, ...
+    double tz[TR], th[TR], tpm[TR], tpn[TR], tub[TR], tvb[TR], tdu[TR], tdv[TR];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < TR; r++) {
         const int t = tid + r * NT;
         const int y = t / F_PX, x = t - y * F_PX, gi = I0 - 2 + x, gj = J0 - 2 + y;
         const bool on = t < F_N;
@@ -396,7 +396,7 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
     // ---- (2) staged tiles: Drhs (advance_2d.cpp:149-152), ubar / vbar(krhs), pm, pn
     double *tl = lds;
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < TR; r++) {
         const int t = tid + r * NT;
         if (t < F_N) {
             tl[T_D * F_N + t] = tz[r] + th[r];
@@ -406,7 +406,7 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
     __syncthreads();
     // ---- (3) DUon, DVom on the tile (:153-166)
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
+    for (int r = 0; r < TR; r++) {
         const int t = tid + r * NT;
         if (t < F_N) {
             const int y = t / F_PX, x = t - y * F_PX, gi = I0 - 2 + x, gj = J0 - 2 + y;
