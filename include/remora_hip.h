@@ -248,6 +248,26 @@ int  rh_init_state(rh_ctx *ctx, rh_state *s, const rh_init_params *ip);
  * (device output buffer, FAB order) */
 int  rh_plot_vars(rh_ctx *ctx, rh_state *s, int with_scalar, double *out_device);
 
+/* ---- AMReX-native plotfile output (outside the hot path; so that amrex_fcompare / yt / VisIt read the results) ----
+ * REMORA::WritePlotFile, WriteMultiLevelPlotfileWithBathymetry, WriteGenericPlotfileHeaderWithBathymetry
+ * (Source/IO/REMORA_Plotfile.cpp:141-605), one level, the reference's default variables (temp, salt, [scalar], x/y/z_velocity)
+ * plus the nodal mesh-height block "Nu_nd" (z_phys_nd - k dz, REMORA_Plotfile.cpp:320-329). */
+typedef struct rh_plot_box {
+    rh_box box;                          /* the rank's valid cell box */
+    int    file_index;                   /* data went to Level_0/Cell_D_<index> and Level_0/Nu_nd_D_<index> */
+    long   cell_offset, nd_offset;       /* byte offsets of the two FAB records in those files */
+    double cell_min[6], cell_max[6], nd_min[3], nd_max[3];
+} rh_plot_box;
+/* This rank's part: gathers the variables on the device, appends one FAB record to each of the two data files under
+ * <dir>/Level_0 (created if needed) and fills *out.  Synchronises. */
+int  rh_plotfile_write_data(rh_ctx *ctx, rh_state *s, const char *dir, int with_scalar, int file_index, rh_plot_box *out);
+/* Header, Level_0/Cell_H and Level_0/Nu_nd_H for the boxes of all ranks (host only; needs no device).  A decomposed run gathers
+ * the rh_plot_box records with its own communicator and calls this on one rank. */
+int  rh_plotfile_write_headers(const rh_params *prm, const char *dir, int with_scalar, int step, double time,
+                               int nboxes, const rh_plot_box *boxes);
+/* Single-box convenience: both of the above. */
+int  rh_write_plotfile(rh_ctx *ctx, rh_state *s, const char *dir, int with_scalar, int step, double time);
+
 /* per-kernel timing: HIP events recorded on the context's stream around every launch of the named kernel group */
 int  rh_timing_enable(rh_ctx *ctx, int on);
 int  rh_timing_report(rh_ctx *ctx, char *buf, int buflen);        /* JSON: {"kernel":{"calls":n,"ms":t},...}; synchronises */

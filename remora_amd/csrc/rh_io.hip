@@ -1,0 +1,169 @@
+// rh_io.hip -- AMReX-native plotfile output of the state, so that results can be read by the reference's own tooling
+// (amrex_fcompare, yt, VisIt): REMORA::WritePlotFile / WriteMultiLevelPlotfileWithBathymetry / WriteGenericPlotfileHeaderWithBathymetry,
+// Source/IO/REMORA_Plotfile.cpp:141-605, for one level.  Layout:
+//   <dir>/Header                       text: variables, geometry, one RealBox per box, the nodal "Nu_nd" block
+//   <dir>/Level_0/Cell_H, Nu_nd_H      VisMF headers: box list, "FabOnDisk: <file> <offset>", per-box minima and maxima
+//   <dir>/Level_0/Cell_D_nnnnn         "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))<box> <ncomp>\n" + native doubles
+//   <dir>/Level_0/Nu_nd_D_nnnnn        the same for the 3-component nodal mesh displacement (0, 0, z_phys_nd - k dz)
+// The variables are gathered on the device (two kernels), copied to the host once and written with stdio; only this file and the
+// diagnostics synchronise.  Every rank writes its own data file; the headers take the list of all boxes (rank 0, after a gather).
+#include "rh_common.h"
+#include <sstream>
+#include <sys/stat.h>
+#include <cerrno>
+
+// nodal mesh height: z_phys_nd of Utils/REMORA_DepthStretchTransform.H:204-236 (average of the four w-columns around the node; the
+// z_w array carries three ghost columns, so the clamped branch of :233-236 is never taken on the nodes of a valid box) minus the
+// uniform-grid height k dz (REMORA_Plotfile.cpp:320-329)
+__global__ void k_plot_nd(B3 nb, A4 z_w, double *__restrict__ out, double dz)
+{
+    RH_IJ(nb); if (!inb2(nb, i, j)) return;
+    const int k = nb.lo2 + RH_KZ;
+    const long nx = nb.hi0 - nb.lo0 + 1, ny = nb.hi1 - nb.lo1 + 1, nz = nb.hi2 - nb.lo2 + 1, n3 = nx * ny * nz;
+    const long q = (long)(i - nb.lo0) + (long)(j - nb.lo1) * nx + (long)(k - nb.lo2) * nx * ny;
+    double z = 0.25 * (z_w(i, j, k) + z_w(i + 1, j, k) + z_w(i, j + 1, k) + z_w(i + 1, j + 1, k));
+    z -= k * dz;
+    out[q] = 0.0; out[n3 + q] = 0.0; out[2 * n3 + q] = z;
+}
+
+static int make_dir(const std::string &d)
+{
+    if (mkdir(d.c_str(), 0777) != 0 && errno != EEXIST) return rh_fail("plotfile: cannot create directory %s: %s", d.c_str(), strerror(errno));
+    return 0;
+}
+static std::string box_str(const rh_box &b, int nodal)
+{
+    char s[160];
+    snprintf(s, sizeof s, "((%d,%d,%d) (%d,%d,%d) (%d,%d,%d))", b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2], nodal, nodal, nodal);
+    return s;
+}
+// one FAB record appended to `path`; returns the offset it starts at
+static int write_fab(const std::string &path, const rh_box &b, int nodal, int ncomp, const double *data, long *offset)
+{
+    FILE *f = fopen(path.c_str(), "ab");
+    if (!f) return rh_fail("plotfile: cannot open %s: %s", path.c_str(), strerror(errno));
+    fseek(f, 0, SEEK_END);
+    *offset = ftell(f);
+    fprintf(f, "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))%s %d\n", box_str(b, nodal).c_str(), ncomp);
+    const size_t n = (size_t)bx_npts(b) * ncomp;
+    const size_t w = fwrite(data, sizeof(double), n, f);
+    if (fclose(f) != 0 || w != n) return rh_fail("plotfile: short write to %s", path.c_str());
+    return 0;
+}
+static void min_max(const double *d, long n3, int ncomp, double *mn, double *mx)
+{
+    for (int c = 0; c < ncomp; c++) {
+        double a = d[c * n3], b = a;
+        for (long q = 1; q < n3; q++) { const double v = d[c * n3 + q]; a = v < a ? v : a; b = v > b ? v : b; }
+        mn[c] = a; mx[c] = b;
+    }
+}
+
+extern "C" int rh_plotfile_write_data(rh_ctx *c, rh_state *s, const char *dir, int with_scalar, int file_index, rh_plot_box *out)
+{
+    if (!dir || !out) return rh_fail("rh_plotfile_write_data: null argument");
+    if (file_index < 0 || file_index > 99999) return rh_fail("rh_plotfile_write_data: file_index out of range");
+    const rh_box bx = c->bx;
+    rh_box nb = bx; for (int d = 0; d < 3; d++) nb.hi[d] += 1;                    // surroundingNodes in all directions
+    RH_NEED(s->z_w, bx_grow(bx_nodal(bx, 2), 1, 1, 0));
+    const int nc = with_scalar ? 6 : 5;
+    const long n3 = bx_npts(bx), m3 = bx_npts(nb);
+    double *dbuf = nullptr;
+    RH_HIP(hipMalloc((void **)&dbuf, sizeof(double) * (size_t)(nc * n3 + 3 * m3)));
+    int rc = rh_plot_vars(c, s, with_scalar, dbuf);
+    if (!rc) {
+        const double dz = (c->prm.prob_hi[2] - c->prm.prob_lo[2]) / (double)c->nz;
+        k_plot_nd<<<grid3(nb), rh_block(), 0, c->stream>>>(mkB(nb), mkA(s->z_w), dbuf + nc * n3, dz);
+        if (hipGetLastError() != hipSuccess) rc = rh_fail("rh_plotfile_write_data: launch failed");
+    }
+    std::vector<double> h((size_t)(nc * n3 + 3 * m3));
+    if (!rc && hipMemcpyAsync(h.data(), dbuf, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = rh_fail("rh_plotfile_write_data: copy failed");
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = rh_fail("rh_plotfile_write_data: synchronise failed");
+    (void)hipFree(dbuf);
+    if (rc) return rc;
+    const std::string d0 = dir, d1 = d0 + "/Level_0";
+    RH_TRY(make_dir(d0)); RH_TRY(make_dir(d1));
+    char name[64];
+    memset(out, 0, sizeof *out);
+    out->box = bx; out->file_index = file_index;
+    snprintf(name, sizeof name, "/Cell_D_%05d", file_index);
+    RH_TRY(write_fab(d1 + name, bx, 0, nc, h.data(), &out->cell_offset));
+    snprintf(name, sizeof name, "/Nu_nd_D_%05d", file_index);
+    RH_TRY(write_fab(d1 + name, nb, 1, 3, h.data() + nc * n3, &out->nd_offset));
+    min_max(h.data(), n3, nc, out->cell_min, out->cell_max);
+    min_max(h.data() + nc * n3, m3, 3, out->nd_min, out->nd_max);
+    return 0;
+}
+
+// VisMF header (AMReX VisMF::Header, version 1, one FAB per box): what Cell_H / Nu_nd_H hold in the reference's gold files
+static int write_vismf_header(const std::string &path, const char *prefix, int ncomp, int nodal, int nboxes, const rh_plot_box *B)
+{
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) return rh_fail("plotfile: cannot open %s: %s", path.c_str(), strerror(errno));
+    fprintf(f, "1\n1\n%d\n0\n(%d 0\n", ncomp, nboxes);
+    for (int b = 0; b < nboxes; b++) {
+        rh_box x = B[b].box; if (nodal) for (int d = 0; d < 3; d++) x.hi[d] += 1;
+        fprintf(f, "%s\n", box_str(x, nodal).c_str());
+    }
+    fprintf(f, ")\n%d\n", nboxes);
+    for (int b = 0; b < nboxes; b++) fprintf(f, "FabOnDisk: %s_D_%05d %ld\n", prefix, B[b].file_index, nodal ? B[b].nd_offset : B[b].cell_offset);
+    for (int pass = 0; pass < 2; pass++) {
+        fprintf(f, "\n%d,%d\n", nboxes, ncomp);
+        for (int b = 0; b < nboxes; b++) {
+            const double *v = nodal ? (pass ? B[b].nd_max : B[b].nd_min) : (pass ? B[b].cell_max : B[b].cell_min);
+            for (int n = 0; n < ncomp; n++) fprintf(f, "%.16e,", v[n]);
+            fprintf(f, "\n");
+        }
+    }
+    fprintf(f, "\n");
+    return fclose(f) == 0 ? 0 : rh_fail("plotfile: write to %s failed", path.c_str());
+}
+
+extern "C" int rh_plotfile_write_headers(const rh_params *P, const char *dir, int with_scalar, int step, double time, int nboxes, const rh_plot_box *B)
+{
+    if (!P || !dir || !B || nboxes < 1) return rh_fail("rh_plotfile_write_headers: bad argument");
+    const std::string d0 = dir, d1 = d0 + "/Level_0";
+    RH_TRY(make_dir(d0)); RH_TRY(make_dir(d1));
+    const int nc = with_scalar ? 6 : 5;
+    double dx[3];
+    for (int d = 0; d < 3; d++) dx[d] = (P->prob_hi[d] - P->prob_lo[d]) / (double)(P->domain_hi[d] - P->domain_lo[d] + 1);
+    std::ostringstream H; H.precision(17);                                        // REMORA_Plotfile.cpp:520-605
+    H << "HyperCLaw-V1.1" << '\n' << nc << '\n';
+    H << "temp\nsalt\n"; if (with_scalar) H << "scalar\n";
+    H << "x_velocity\ny_velocity\nz_velocity\n";
+    H << 3 << '\n' << time << '\n' << 0 << '\n';
+    for (int d = 0; d < 3; d++) H << P->prob_lo[d] << ' ';
+    H << '\n';
+    for (int d = 0; d < 3; d++) H << P->prob_hi[d] << ' ';
+    H << '\n' << '\n';                                                            // (no refinement ratios on one level)
+    rh_box dom; for (int d = 0; d < 3; d++) { dom.lo[d] = P->domain_lo[d]; dom.hi[d] = P->domain_hi[d]; }
+    H << box_str(dom, 0) << ' ' << '\n' << step << ' ' << '\n';
+    for (int d = 0; d < 3; d++) H << dx[d] << ' ';
+    H << '\n' << 0 << '\n' << "0\n";
+    H << 0 << ' ' << nboxes << ' ' << time << '\n' << step << '\n';
+    for (int b = 0; b < nboxes; b++)
+        for (int d = 0; d < 3; d++) {                                             // amrex::RealBox(b, dx, prob_lo), box shifted to the domain's origin
+            const double lo = P->prob_lo[d] + dx[d] * (double)(B[b].box.lo[d] - P->domain_lo[d]);
+            const double hi = P->prob_lo[d] + dx[d] * (double)(B[b].box.hi[d] - P->domain_lo[d] + 1);
+            H << lo << ' ' << hi << '\n';
+        }
+    H << "Level_0/Cell" << '\n' << "1\n3\namrexvec_nu_x\namrexvec_nu_y\namrexvec_nu_z\n" << "Level_0/Nu_nd" << '\n';
+    FILE *f = fopen((d0 + "/Header").c_str(), "w");
+    if (!f) return rh_fail("plotfile: cannot open %s/Header: %s", dir, strerror(errno));
+    const std::string hs = H.str();
+    const size_t w = fwrite(hs.data(), 1, hs.size(), f);
+    if (fclose(f) != 0 || w != hs.size()) return rh_fail("plotfile: write to %s/Header failed", dir);
+    RH_TRY(write_vismf_header(d1 + "/Cell_H", "Cell", nc, 0, nboxes, B));
+    return write_vismf_header(d1 + "/Nu_nd_H", "Nu_nd", 3, 1, nboxes, B);
+}
+
+extern "C" int rh_write_plotfile(rh_ctx *c, rh_state *s, const char *dir, int with_scalar, int step, double time)
+{
+    if (c->prm.nranks[0] * c->prm.nranks[1] > 1)
+        return rh_fail("rh_write_plotfile: decomposed runs gather their rh_plot_box records and call rh_plotfile_write_headers on one rank");
+    // start from empty data files: the writer appends
+    if (dir) { const std::string d1 = std::string(dir) + "/Level_0"; (void)remove((d1 + "/Cell_D_00000").c_str()); (void)remove((d1 + "/Nu_nd_D_00000").c_str()); }
+    rh_plot_box b;
+    RH_TRY(rh_plotfile_write_data(c, s, dir, with_scalar, 0, &b));
+    return rh_plotfile_write_headers(&c->prm, dir, with_scalar, step, time, 1, &b);
+}

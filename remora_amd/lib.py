@@ -87,6 +87,11 @@ class HaloPlan(C.Structure):
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p)
 
 
+class PlotBox(C.Structure):
+    _fields_ = [("box", Box), ("file_index", C.c_int), ("cell_offset", C.c_long), ("nd_offset", C.c_long),
+                ("cell_min", C.c_double * 6), ("cell_max", C.c_double * 6), ("nd_min", C.c_double * 3), ("nd_max", C.c_double * 3)]
+
+
 class RemoraHipError(RuntimeError):
     pass
 
@@ -124,6 +129,9 @@ SIGNATURES = {
     "rh_prestep_t": (C.c_int, [_P, Box] + [_A] * 11 + [C.c_int, C.c_int, C.c_int, C.c_double]),
     "rh_prestep_uv": (C.c_int, [_P, Box, C.c_int, C.c_int] + [_A] * 8 + [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]),
     "rh_t3dmix": (C.c_int, [_P, Box] + [_A] * 8 + [C.c_double, C.c_int]),
+    "rh_plotfile_write_data": (C.c_int, [_P, C.POINTER(State), C.c_char_p, C.c_int, C.c_int, C.POINTER(PlotBox)]),
+    "rh_plotfile_write_headers": (C.c_int, [C.POINTER(Params), C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(PlotBox)]),
+    "rh_write_plotfile": (C.c_int, [_P, C.POINTER(State), C.c_char_p, C.c_int, C.c_int, C.c_double]),
     "rh_gls_prestep": (C.c_int, [_P, C.POINTER(State), _A, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rh_gls_corrector": (C.c_int, [_P, C.POINTER(State), _A, C.c_int, C.c_int]),
     "rh_coriolis": (C.c_int, [_P, Box, Box] + [_A] * 6 + [C.c_int, C.c_int]),

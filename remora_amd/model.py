@@ -245,6 +245,16 @@ class REMORA:
         self.sync()
         return out.cpu().numpy()
 
+    def WritePlotFile(self, dirname, with_scalar=False):
+        """REMORA::WritePlotFile (IO/REMORA_Plotfile.cpp:141-433): AMReX-native plotfile of the current state (single box)."""
+        L.check(self.lib.rh_write_plotfile(self.ctx, C.byref(self.state), str(dirname).encode(), int(with_scalar), self.istep, self.t_new))
+
+    def write_plot_data(self, dirname, file_index, with_scalar=False):
+        """This rank's FAB records of a decomposed run; returns the PlotBox record for rh_plotfile_write_headers."""
+        pb = L.PlotBox()
+        L.check(self.lib.rh_plotfile_write_data(self.ctx, C.byref(self.state), str(dirname).encode(), int(with_scalar), file_index, C.byref(pb)))
+        return pb
+
     # ---- reductions around the step ------------------------------------------------------------------------
     def estTimeStep(self, cfl=0.8, local_only=False):
         """REMORA::estTimeStep (REMORA_ComputeTimestep.cpp:39-95)."""

@@ -64,6 +64,15 @@ def main():
         mine[f] = (a, lo, hi)
     gathered = [None] * world
     dist.gather_object((ilo, ihi, jlo, jhi, mine), gathered if rank == 0 else None, dst=0)
+    # plotfile of the decomposed run: every rank appends its FAB records to its own data files, rank 0 writes the headers
+    import ctypes as C
+    import tempfile
+    from remora_amd import lib as L
+    pdir = [tempfile.mkdtemp(prefix="rh_plt_") if rank == 0 else None]
+    dist.broadcast_object_list(pdir, src=0)
+    pb = rem.write_plot_data(pdir[0], rank) if ncalls < 0 else None
+    pbs = [None] * world
+    dist.gather_object(bytes(pb) if pb is not None else None, pbs if rank == 0 else None, dst=0)
     ok = True
     if rank == 0:
         ref = REMORA(cfg, device="cuda:0")
@@ -100,6 +109,17 @@ def main():
                     w = np.argwhere(x != y)
                     print(f"MISMATCH {case} field {f} box i {silo}-{sihi} j {sjlo}-{sjhi}: max |diff| = {np.nanmax(np.abs(x - y)):.3e} at {len(w)} points; "
                           f"comps {sorted(set(int(v) for v in w[:, 0]))} i {sorted(set(int(v) for v in w[:, 3] + i0))[:12]} j {sorted(set(int(v) for v in w[:, 2] + j0))[:12]}", flush=True)
+        if ncalls < 0:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from plotfile import read_plotfile
+            B = (L.PlotBox * world)(*[L.PlotBox.from_buffer_copy(b) for b in pbs])
+            L.check(rem.lib.rh_plotfile_write_headers(C.byref(rem.params), pdir[0].encode(), 0, rem.istep, rem.t_new, world, B))
+            _, stitched = read_plotfile("", root=pdir[0])
+            if not np.array_equal(stitched, ref.plot()):
+                ok = False
+                print(f"MISMATCH {case}: plotfile stitched from {world} boxes differs from the single-box plot variables", flush=True)
+            import shutil
+            shutil.rmtree(pdir[0], ignore_errors=True)
         print(("DECOMP_OK" if ok else "DECOMP_FAIL"), case, "world", world, "steps", nsteps, flush=True)
         ref.close()
     rem.close()

@@ -7,17 +7,20 @@ import numpy as np
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def read_plotfile(case):
-    d = os.path.join(GOLD, case)
+def read_plotfile(case, root=None, nodal=False):
+    """Cell data [comp, k, j, i] of a plotfile directory (default: tests/golden/<case>); nodal=True reads the Nu_nd block."""
+    d = os.path.join(GOLD if root is None else root, case)
     with open(os.path.join(d, "Header")) as f:
         lines = f.read().split("\n")
     ncomp = int(lines[1])
     names = lines[2:2 + ncomp]
     dom = re.findall(r"\(\((-?\d+),(-?\d+),(-?\d+)\) \((-?\d+),(-?\d+),(-?\d+)\)", "\n".join(lines))[0]
     lo = tuple(int(x) for x in dom[:3]); hi = tuple(int(x) for x in dom[3:])
+    if nodal:
+        hi = tuple(h + 1 for h in hi); ncomp = 3; names = ["amrexvec_nu_x", "amrexvec_nu_y", "amrexvec_nu_z"]
     shape = (hi[2] - lo[2] + 1, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1)
     out = np.full((ncomp,) + shape, np.nan)
-    with open(os.path.join(d, "Level_0", "Cell_H")) as f:
+    with open(os.path.join(d, "Level_0", "Nu_nd_H" if nodal else "Cell_H")) as f:
         ch = f.read()
     for fname, off in re.findall(r"FabOnDisk: (\S+) (\d+)", ch):
         with open(os.path.join(d, "Level_0", fname), "rb") as f:
