@@ -268,6 +268,15 @@ int  rh_plotfile_write_headers(const rh_params *prm, const char *dir, int with_s
 /* Single-box convenience: both of the above. */
 int  rh_write_plotfile(rh_ctx *ctx, rh_state *s, const char *dir, int with_scalar, int step, double time);
 
+/* Checkpoint / restart in the reference's layout (REMORA::WriteCheckpointFile / ReadCheckpointFile, Source/IO/REMORA_Checkpoint.cpp:
+ * 15-245, 248-470): text Header + one VisMF (<Name>_H, <Name>_D_00000) per array under <dir>/Level_0, every array with its ghost
+ * cells as the reference writes them (Cell, Cell_old, XFace, ..., XRHS, XBar, DU_avg1, zeta, Zt_avg1, h, Akv, Akt and, with the GLS
+ * closure, tke, gls, Lscale, Akk, Akp).  rh_read_checkpoint expects a state that already holds what InitData builds without a
+ * checkpoint (rh_init_state or the host's init), overwrites the checkpointed arrays and rebuilds z_w / z_r / Hz; a run continued
+ * from it is bit-identical to the uninterrupted one.  One box per call; both synchronise. */
+int  rh_write_checkpoint(rh_ctx *ctx, rh_state *s, const char *dir, int step, double time);
+int  rh_read_checkpoint(rh_ctx *ctx, rh_state *s, const char *dir, int *step, double *time);
+
 /* per-kernel timing: HIP events recorded on the context's stream around every launch of the named kernel group */
 int  rh_timing_enable(rh_ctx *ctx, int on);
 int  rh_timing_report(rh_ctx *ctx, char *buf, int buflen);        /* JSON: {"kernel":{"calls":n,"ms":t},...}; synchronises */

@@ -167,3 +167,144 @@ extern "C" int rh_write_plotfile(rh_ctx *c, rh_state *s, const char *dir, int wi
     RH_TRY(rh_plotfile_write_data(c, s, dir, with_scalar, 0, &b));
     return rh_plotfile_write_headers(&c->prm, dir, with_scalar, step, time, 1, &b);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Checkpoint / restart: REMORA::WriteCheckpointFile / ReadCheckpointFile, Source/IO/REMORA_Checkpoint.cpp:15-245,248-470.
+// The reference writes every MultiFab WITH its ghost cells (the copies keep nGrowVect, :115-202), one VisMF per array under
+// <dir>/Level_0/<Name>_{H,D_00000}, and a text Header (:57-106).  A native rh_array4 is already one FAB in that memory order, so a
+// record is the array as it stands.  Single box per call; a decomposed run passes its rank as file_index and a directory per rank
+// or writes the headers itself (the per-array headers list one box).
+struct ChkField { const char *name; rh_array4 rh_state::*m; int ix0, ix1, ix2; int gls_only; };
+static const ChkField g_chk[] = {
+    {"Cell", &rh_state::cons_new, 0, 0, 0, 0}, {"Cell_old", &rh_state::cons_old, 0, 0, 0, 0},
+    {"XFace", &rh_state::xvel_new, 1, 0, 0, 0}, {"XFace_old", &rh_state::xvel_old, 1, 0, 0, 0},
+    {"YFace", &rh_state::yvel_new, 0, 1, 0, 0}, {"YFace_old", &rh_state::yvel_old, 0, 1, 0, 0},
+    {"ZFace", &rh_state::zvel_new, 0, 0, 1, 0}, {"ZFace_old", &rh_state::zvel_old, 0, 0, 1, 0},
+    {"XRHS", &rh_state::ru, 1, 0, 0, 0}, {"YRHS", &rh_state::rv, 0, 1, 0, 0},
+    {"XBar", &rh_state::ubar, 1, 0, 0, 0}, {"YBar", &rh_state::vbar, 0, 1, 0, 0},
+    {"XRHS2d", &rh_state::ru2d, 1, 0, 0, 0}, {"YRHS2d", &rh_state::rv2d, 0, 1, 0, 0},
+    {"Mskr", &rh_state::mskr, 0, 0, 0, 0}, {"Msku", &rh_state::msku, 1, 0, 0, 0}, {"Mskv", &rh_state::mskv, 0, 1, 0, 0},
+    {"rdrag", &rh_state::rdrag, 0, 0, 0, 0},
+    {"DU_avg1", &rh_state::DU_avg1, 1, 0, 0, 0}, {"DU_avg2", &rh_state::DU_avg2, 1, 0, 0, 0},
+    {"DV_avg1", &rh_state::DV_avg1, 0, 1, 0, 0}, {"DV_avg2", &rh_state::DV_avg2, 0, 1, 0, 0},
+    {"zeta", &rh_state::zeta, 0, 0, 0, 0}, {"Zt_avg1", &rh_state::Zt_avg1, 0, 0, 0, 0}, {"h", &rh_state::h, 0, 0, 0, 0},
+    {"tke", &rh_state::tke, 0, 0, 1, 1}, {"gls", &rh_state::gls, 0, 0, 1, 1}, {"Lscale", &rh_state::Lscale, 0, 0, 1, 1},
+    {"Akk", &rh_state::Akk, 0, 0, 1, 1}, {"Akp", &rh_state::Akp, 0, 0, 1, 1},
+    {"Akv", &rh_state::Akv, 0, 0, 1, 0}, {"Akt", &rh_state::Akt, 0, 0, 1, 0},
+};
+static std::string box_str_ix(const rh_box &b, int ix0, int ix1, int ix2)
+{
+    char s[160];
+    snprintf(s, sizeof s, "((%d,%d,%d) (%d,%d,%d) (%d,%d,%d))", b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2], ix0, ix1, ix2);
+    return s;
+}
+
+extern "C" int rh_write_checkpoint(rh_ctx *c, rh_state *s, const char *dir, int step, double time)
+{
+    if (!dir) return rh_fail("rh_write_checkpoint: null directory");
+    const std::string d0 = dir, d1 = d0 + "/Level_0";
+    RH_TRY(make_dir(d0)); RH_TRY(make_dir(d1));
+    RH_HIP(hipStreamSynchronize(c->stream));
+    std::vector<double> h;
+    for (const ChkField &f : g_chk) {
+        const rh_array4 &a = s->*(f.m);
+        if (f.gls_only && c->prm.vmix_mode != RH_VMIX_GLS) continue;
+        if (!a.p) return rh_fail("rh_write_checkpoint: state array %s is not bound", f.name);
+        const MFV m = mfv(c, a, f.ix0, f.ix1, f.ix2);
+        const long n = a4_size(a), n3 = n / a.ncomp;
+        h.resize((size_t)n);
+        RH_HIP(hipMemcpy(h.data(), a.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+        const std::string base = d1 + "/" + f.name;
+        FILE *fd = fopen((base + "_D_00000").c_str(), "wb");
+        if (!fd) return rh_fail("rh_write_checkpoint: cannot open %s_D_00000: %s", base.c_str(), strerror(errno));
+        fprintf(fd, "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))%s %d\n", box_str_ix(bx_of(a), f.ix0, f.ix1, f.ix2).c_str(), a.ncomp);
+        const size_t w = fwrite(h.data(), sizeof(double), (size_t)n, fd);
+        if (fclose(fd) != 0 || w != (size_t)n) return rh_fail("rh_write_checkpoint: short write to %s_D_00000", base.c_str());
+        // VisMF header: version, how, ncomp, ghost widths, box list (valid boxes), FabOnDisk, minima, maxima (over the whole FAB)
+        FILE *fh = fopen((base + "_H").c_str(), "w");
+        if (!fh) return rh_fail("rh_write_checkpoint: cannot open %s_H", base.c_str());
+        fprintf(fh, "1\n1\n%d\n", a.ncomp);
+        if (m.ng[0] == m.ng[1] && m.ng[1] == m.ng[2]) fprintf(fh, "%d\n", m.ng[0]); else fprintf(fh, "(%d,%d,%d)\n", m.ng[0], m.ng[1], m.ng[2]);
+        fprintf(fh, "(1 0\n%s\n)\n1\nFabOnDisk: %s_D_00000 0\n", box_str_ix(m.valid, f.ix0, f.ix1, f.ix2).c_str(), f.name);
+        std::vector<double> mn(a.ncomp), mx(a.ncomp);
+        min_max(h.data(), n3, a.ncomp, mn.data(), mx.data());
+        for (int pass = 0; pass < 2; pass++) {
+            fprintf(fh, "\n1,%d\n", a.ncomp);
+            for (int q = 0; q < a.ncomp; q++) fprintf(fh, "%.16e,", pass ? mx[q] : mn[q]);
+            fprintf(fh, "\n");
+        }
+        fprintf(fh, "\n");
+        if (fclose(fh) != 0) return rh_fail("rh_write_checkpoint: write to %s_H failed", base.c_str());
+    }
+    std::ostringstream H; H.precision(17);                                        // REMORA_Checkpoint.cpp:57-106
+    H << "Checkpoint file for REMORA\n" << 0 << "\n" << RH_NCONS << "\n" << 1 << "\n" << 1 << "\n" << 1 << "\n" << 2 << "\n" << 2 << "\n" << 3 << "\n" << 3 << "\n";
+    H << step << " \n" << c->prm.dt << " \n" << time << " \n";
+    H << "(1 0\n" << box_str_ix(c->bx, 0, 0, 0) << "\n)\n" << '\n';
+    FILE *f = fopen((d0 + "/Header").c_str(), "w");
+    if (!f) return rh_fail("rh_write_checkpoint: cannot open %s/Header", dir);
+    const std::string hs = H.str();
+    const size_t w = fwrite(hs.data(), 1, hs.size(), f);
+    if (fclose(f) != 0 || w != hs.size()) return rh_fail("rh_write_checkpoint: write to %s/Header failed", dir);
+    return 0;
+}
+
+// Restart: the state must already hold what InitData builds without a checkpoint (metrics, Coriolis, mixing coefficients, masks:
+// rh_init_state or the host's own init); this call overwrites the checkpointed arrays, ghost cells included, and rebuilds the
+// vertical grid from the restored h and Zt_avg1 (REMORA_Checkpoint.cpp:248-470, then stretch_transform as in REMORA::restart).
+extern "C" int rh_read_checkpoint(rh_ctx *c, rh_state *s, const char *dir, int *step, double *time)
+{
+    if (!dir) return rh_fail("rh_read_checkpoint: null directory");
+    const std::string d0 = dir, d1 = d0 + "/Level_0";
+    {
+        FILE *f = fopen((d0 + "/Header").c_str(), "r");
+        if (!f) return rh_fail("rh_read_checkpoint: cannot open %s/Header: %s", dir, strerror(errno));
+        char line[256]; int finest = -1, nc[8], st = 0; double dt = 0, t = 0;
+        bool ok = fgets(line, sizeof line, f) && strncmp(line, "Checkpoint file for REMORA", 26) == 0 && fscanf(f, "%d", &finest) == 1;
+        for (int q = 0; ok && q < 8; q++) ok = fscanf(f, "%d", &nc[q]) == 1;
+        ok = ok && fscanf(f, "%d %lf %lf", &st, &dt, &t) == 3;
+        fclose(f);
+        if (!ok) return rh_fail("rh_read_checkpoint: %s/Header is not a REMORA checkpoint header", dir);
+        if (finest != 0) return rh_fail("rh_read_checkpoint: %d levels in the checkpoint; one level is supported", finest + 1);
+        if (nc[0] != RH_NCONS) return rh_fail("rh_read_checkpoint: checkpoint holds %d tracers, this build %d", nc[0], RH_NCONS);
+        if (step) *step = st;
+        if (time) *time = t;
+    }
+    std::vector<double> h;
+    for (const ChkField &f : g_chk) {
+        const rh_array4 &a = s->*(f.m);
+        if (f.gls_only && c->prm.vmix_mode != RH_VMIX_GLS) continue;
+        if (!a.p) return rh_fail("rh_read_checkpoint: state array %s is not bound", f.name);
+        const std::string base = d1 + "/" + f.name;
+        long off = -1; char fname[128] = "";
+        {
+            FILE *fh = fopen((base + "_H").c_str(), "r");
+            if (!fh) return rh_fail("rh_read_checkpoint: cannot open %s_H: %s", base.c_str(), strerror(errno));
+            char line[512];
+            while (fgets(line, sizeof line, fh)) if (sscanf(line, "FabOnDisk: %127s %ld", fname, &off) == 2) break;
+            fclose(fh);
+            if (off < 0) return rh_fail("rh_read_checkpoint: no FabOnDisk record in %s_H", base.c_str());
+        }
+        FILE *fd = fopen((d1 + "/" + fname).c_str(), "rb");
+        if (!fd) return rh_fail("rh_read_checkpoint: cannot open %s/%s", d1.c_str(), fname);
+        fseek(fd, off, SEEK_SET);
+        char hdr[512];
+        if (!fgets(hdr, sizeof hdr, fd)) { fclose(fd); return rh_fail("rh_read_checkpoint: %s: no FAB header", fname); }
+        const char *p = strstr(hdr, ")))");                                       // end of the real descriptor
+        int lo[3], hi[3], ix[3], ncomp = 0;
+        if (!p || sscanf(p + 3, "((%d,%d,%d) (%d,%d,%d) (%d,%d,%d)) %d", &lo[0], &lo[1], &lo[2], &hi[0], &hi[1], &hi[2], &ix[0], &ix[1], &ix[2], &ncomp) != 10 ||
+            strncmp(hdr, "FAB ((8, (64 11 52 0 1 12 0 1023)),(8, (8 7 6 5 4 3 2 1)))", 58) != 0) {
+            fclose(fd); return rh_fail("rh_read_checkpoint: %s: not a native little-endian double FAB", fname);
+        }
+        bool same = ncomp == a.ncomp;
+        for (int d = 0; d < 3; d++) same = same && lo[d] == a.lo[d] && hi[d] == a.hi[d];
+        if (!same) { fclose(fd); return rh_fail("rh_read_checkpoint: %s holds box (%d,%d,%d)-(%d,%d,%d) x %d, the state array (%d,%d,%d)-(%d,%d,%d) x %d (same decomposition and ghost widths are required)",
+                                                fname, lo[0], lo[1], lo[2], hi[0], hi[1], hi[2], ncomp, a.lo[0], a.lo[1], a.lo[2], a.hi[0], a.hi[1], a.hi[2], a.ncomp); }
+        const long n = a4_size(a);
+        h.resize((size_t)n);
+        const size_t r = fread(h.data(), sizeof(double), (size_t)n, fd);
+        fclose(fd);
+        if (r != (size_t)n) return rh_fail("rh_read_checkpoint: %s is truncated", fname);
+        RH_HIP(hipMemcpy(a.p, h.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    }
+    return rh_stretch_transform(c, s);
+}

@@ -132,6 +132,8 @@ SIGNATURES = {
     "rh_plotfile_write_data": (C.c_int, [_P, C.POINTER(State), C.c_char_p, C.c_int, C.c_int, C.POINTER(PlotBox)]),
     "rh_plotfile_write_headers": (C.c_int, [C.POINTER(Params), C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_int, C.POINTER(PlotBox)]),
     "rh_write_plotfile": (C.c_int, [_P, C.POINTER(State), C.c_char_p, C.c_int, C.c_int, C.c_double]),
+    "rh_write_checkpoint": (C.c_int, [_P, C.POINTER(State), C.c_char_p, C.c_int, C.c_double]),
+    "rh_read_checkpoint": (C.c_int, [_P, C.POINTER(State), C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "rh_gls_prestep": (C.c_int, [_P, C.POINTER(State), _A, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rh_gls_corrector": (C.c_int, [_P, C.POINTER(State), _A, C.c_int, C.c_int]),
     "rh_coriolis": (C.c_int, [_P, Box, Box] + [_A] * 6 + [C.c_int, C.c_int]),

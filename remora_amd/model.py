@@ -249,6 +249,20 @@ class REMORA:
         """REMORA::WritePlotFile (IO/REMORA_Plotfile.cpp:141-433): AMReX-native plotfile of the current state (single box)."""
         L.check(self.lib.rh_write_plotfile(self.ctx, C.byref(self.state), str(dirname).encode(), int(with_scalar), self.istep, self.t_new))
 
+    def WriteCheckpointFile(self, dirname):
+        """REMORA::WriteCheckpointFile (IO/REMORA_Checkpoint.cpp:15-245)."""
+        L.check(self.lib.rh_write_checkpoint(self.ctx, C.byref(self.state), str(dirname).encode(), self.istep, self.t_new))
+
+    def ReadCheckpointFile(self, dirname):
+        """REMORA::ReadCheckpointFile + restart (IO/REMORA_Checkpoint.cpp:248-470): InitData for the arrays no checkpoint
+        holds, then the checkpointed arrays, the step counter and the clock."""
+        self.InitData()
+        st, t = C.c_int(), C.c_double()
+        L.check(self.lib.rh_read_checkpoint(self.ctx, C.byref(self.state), str(dirname).encode(), C.byref(st), C.byref(t)))
+        self.istep = st.value
+        self.t_new = t.value
+        self.t_old = t.value - self.dt
+
     def write_plot_data(self, dirname, file_index, with_scalar=False):
         """This rank's FAB records of a decomposed run; returns the PlotBox record for rh_plotfile_write_headers."""
         pb = L.PlotBox()
