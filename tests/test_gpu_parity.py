@@ -209,3 +209,26 @@ def test_deep_columns_against_oracle(nz):
         orc.advance(1); rem.timeStep()
         _check(compare_states(orc, rem), "Seamount", f"nz {nz} step {step}")
     rem.close(); orc.close()
+
+
+@pytest.mark.parametrize("case,ncell", [("Upwelling_GLS", (150, 133, 12)), ("Seamount", (197, 135, 13)), ("DoubleGyre", (140, 150, 6))])
+def test_many_tiles_against_oracle(case, ncell):
+    """Every gold case is at most 81 cells wide, i.e. one or two 64-lane tiles in i.  The same physics on grids of several tiles
+    in both directions with ragged last tiles (150 = 2 x 64 + 22, 197 = 3 x 63 + 8 for the overlapped-lane kernels), three steps,
+    all fields incl. ghost cells: exercises the tile seams, the XCD-aware tile order and the patch order of the k-marching kernels."""
+    cfg = cases.get(case)
+    nx0, ny0, _ = cfg["ncell"]
+    cfg["prob_hi"] = (cfg["prob_hi"][0] * ncell[0] / nx0, cfg["prob_hi"][1] * ncell[1] / ny0, cfg["prob_hi"][2])   # same dx, dy
+    cfg["ncell"] = ncell
+    orc = Oracle(cfg); rem = REMORA(cfg)
+    upload_oracle_state(orc, rem)
+    fields = COMPARE + (GLS_FIELDS if "gls" in cfg else [])
+    for step in range(3):
+        orc.advance(1); rem.timeStep()
+        res = compare_states(orc, rem, fields)
+        if "gls" in cfg:
+            bad = {k: v for k, v in res.items() if not (v[0] <= 1e-12 * (step + 1) * max(v[1], 1e-300) or v[0] <= 1e-18)}
+            assert not bad, f"{case} {ncell} step {step}: {bad}"
+        else:
+            _check(res, case, f"{ncell} step {step}")
+    rem.close(); orc.close()
