@@ -70,6 +70,11 @@ void comm_release(rh_ctx *c)
 int comm_exchange(rh_ctx *c, long n_lo, int peer_lo, long n_hi, int peer_hi)
 {
     double *s_lo = c->d_xbuf, *s_hi = c->d_xbuf + c->xcap, *r_lo = c->d_xbuf + 2 * c->xcap, *r_hi = c->d_xbuf + 3 * c->xcap;
+    // one communicator, two streams (compute and the side stream of halo_async_*): its operations run in issue order on every
+    // rank, so an exchange issued on the other stream than the previous one first waits for that one
+    if (c->comm_used && c->last_comm_stream != c->stream) RH_HIP(hipStreamWaitEvent(c->stream, c->ev_comm, 0));
+    struct Mark { rh_ctx *c; ~Mark() { if (!c->ev_comm) (void)hipEventCreateWithFlags(&c->ev_comm, hipEventDisableTiming);
+                                        (void)hipEventRecord(c->ev_comm, c->stream); c->last_comm_stream = c->stream; c->comm_used = true; } } mark{c};
     if (c->xfn) {
         const int r = c->xfn(c->xuser, s_lo, r_lo, n_lo, n_lo > 0 ? peer_lo : -1, s_hi, r_hi, n_hi, n_hi > 0 ? peer_hi : -1, (void *)c->stream);
         if (r != 0) return rh_fail("ghost exchange: transport hook returned %d", r);

@@ -149,6 +149,12 @@ struct rh_ctx {
     rh_exchange_fn xfn = nullptr; void *xuser = nullptr;      // transport of the ghost exchange (RCCL by default)
     double *d_diag = nullptr;                                  // per-block partials of the diagnostics reductions (rh_diag.hip)
     double *d_xbuf = nullptr; long xcap = 0;                   // 4 message slots: send_lo, send_hi, recv_lo, recv_hi (xcap doubles each)
+    // side stream for ghost fills whose consumer is far away (rh_halo.hip: halo_async_*): the fill scope forks off the compute
+    // stream, runs pack -> send/recv -> unpack -> BC passes on xstream with its own message slots, and is joined before the consumer
+    hipStream_t xstream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_comm = nullptr;
+    double *d_xbuf2 = nullptr; long xcap2 = 0;
+    bool async_on = false, async_pending = false, in_advance = false, no_async = false;
+    hipStream_t last_comm_stream = nullptr; bool comm_used = false;
     // per-kernel-group timing
     bool timing = false;
     std::vector<std::string> tnames; std::map<std::string,int> tslot;
@@ -179,6 +185,11 @@ int  halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp);
 int  halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill);
 int  halo_fillpatch(rh_ctx *c, const MFV &m, const rh_array4 &msk, int bccomp, int icomp, int ncomp);
 int  halo_flush(rh_ctx *c);
+// fork: later ghost fills run on the side stream (after everything queued on the compute stream so far); end: back to the compute
+// stream, which does NOT wait; join: the compute stream waits for the side stream's fills (no-op when nothing is pending)
+int  halo_async_begin(rh_ctx *c);
+int  halo_async_end(rh_ctx *c);
+int  halo_async_join(rh_ctx *c);
 // Ghost exchanges and BC passes issued between bc_begin and the matching bc_end are queued and flushed as one launch per dependency level; only
 // ghost-fill calls may sit inside such a scope (any other kernel on the same arrays would overtake the queued passes)
 void bc_begin(rh_ctx *c);

@@ -301,6 +301,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     c->noregsolve = getenv("RH_NOREGSOLVE") && atoi(getenv("RH_NOREGSOLVE")) != 0;
     c->nofuse2d = getenv("RH_NOFUSE2D") && atoi(getenv("RH_NOFUSE2D")) != 0;
     c->gls_libm_pow = getenv("RH_GLS_LIBM_POW") && atoi(getenv("RH_GLS_LIBM_POW")) != 0;
+    c->no_async = getenv("RH_NO_ASYNC") && atoi(getenv("RH_NO_ASYNC")) != 0;
     c->poison = getenv("RH_POISON") && atoi(getenv("RH_POISON")) != 0;
 
     // stretching curves (here N = nz, DepthStretchTransform.H:49)
@@ -352,6 +353,9 @@ extern "C" int rh_destroy(rh_ctx *c)
 {
     if (!c) return 0;
     (void)hipStreamSynchronize(c->stream);
+    if (c->xstream) { (void)hipStreamSynchronize(c->xstream); (void)hipStreamDestroy(c->xstream); }
+    for (hipEvent_t e : {c->ev_fork, c->ev_join, c->ev_comm}) if (e) (void)hipEventDestroy(e);
+    if (c->d_xbuf2) (void)hipFree(c->d_xbuf2);
     for (auto &v : c->tev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &e : c->evpool) (void)hipEventDestroy(e);
     (void)hipFree(c->d_sc); (void)hipFree(c->d_work); if (c->d_xbuf) (void)hipFree(c->d_xbuf); if (c->d_diag) (void)hipFree(c->d_diag);
@@ -365,7 +369,7 @@ extern "C" int rh_weights(const rh_ctx *c, double *w1, double *w2)
     memcpy(w1, c->w1.data(), sizeof(double) * c->w1.size()); memcpy(w2, c->w2.data(), sizeof(double) * c->w2.size());
     return 0;
 }
-extern "C" int rh_sync(rh_ctx *c) { RH_HIP(hipStreamSynchronize(c->stream)); return 0; }
+extern "C" int rh_sync(rh_ctx *c) { RH_TRY(halo_async_join(c)); RH_HIP(hipStreamSynchronize(c->stream)); return 0; }
 
 extern "C" void rh_swap_old_new(rh_state *s)
 {

@@ -138,6 +138,10 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
         RH_TRY(rh_uv3dmix(c, xbx, ybx, s->xvel_new, s->yvel_new, s->xvel_old, s->yvel_old, s->rufrc, s->rvfrc, s->visc2_p, s->visc2_r, s->Hz,
                           s->pm, s->pn, s->mskp, nrhs, 0, dt));
     if (P.vmix_mode == RH_VMIX_GLS) RH_TRY(rh_gls_prestep(c, s, c->W, iic % 2, (iic + 1) % 2, iic, ntfirst));   // :352-357
+    // The ghost cells filled here are first read in advance_3d, a whole barotropic loop later: inside rh_advance the fills go to
+    // the side stream (pack, send/recv, unpack and BC passes overlap the 2-D kernels) and rh_advance_3d_ml joins them.
+    const bool side = c->in_advance && !c->no_async;
+    if (side) RH_TRY(halo_async_begin(c));
     {
         TScope t(c, "halo");
         BcScope bcs(c);
@@ -146,6 +150,7 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
         RH_TRY(halo_fill_boundary(c, mfv(c, s->Hvom, 0, 1, 0), 0, 1));
         RH_TRY(bcs.end());
     }
+    if (side) RH_TRY(halo_async_end(c));
     return 0;
 }
 
@@ -190,6 +195,7 @@ static int advance_3d(rh_ctx *c, rh_state *s, int istep)
 // REMORA::advance_3d_ml, REMORA_advance_3d_ml.cpp:6-71
 extern "C" int rh_advance_3d_ml(rh_ctx *c, rh_state *s, int istep)
 {
+    RH_TRY(halo_async_join(c));                            // the fills setup_step left on the side stream
     TScope tsc(c, "advance_3d_ml");
     {
         TScope t(c, "halo");
@@ -217,7 +223,10 @@ extern "C" int rh_advance_3d_ml(rh_ctx *c, rh_state *s, int istep)
 // REMORA::Advance, REMORA_Advance.cpp:7-35
 extern "C" int rh_advance(rh_ctx *c, rh_state *s, int istep, double t_old)
 {
-    RH_TRY(rh_setup_step(c, s, istep, t_old));
+    c->in_advance = true;
+    const int rc0 = rh_setup_step(c, s, istep, t_old);
+    c->in_advance = false;
+    RH_TRY(rc0);
     if (c->prm.use_barotropic) {
         const int nfast_counter = c->nfast + 1;
         for (int my_iif = 0; my_iif < nfast_counter; my_iif++) RH_TRY(rh_advance_2d_onestep(c, s, istep, my_iif));

@@ -9,8 +9,15 @@
 // ---- periodic wrap: one thread per ghost point of the frame around the valid box -------------------------------
 // Ghost points are enumerated row-wise: first the full-width rows below/above the valid rows, then the two side
 // segments of every valid row.  Source search order (sx, then sy, -1..1) follows the single-box FillBoundary.
-__global__ void k_fill_periodic(A4 a, B3 v, int icomp, int ncomp, int perx, int pery, int lenx, int leny)
+// up to P_BATCH arrays of one fill scope per launch (the three fills that end a barotropic call are one launch, not three)
+#define P_BATCH 8
+struct PFill { A4 a; B3 v; int icomp, ncomp; };
+struct PBatch { int n, perx, pery, lenx, leny; PFill q[P_BATCH]; };
+__global__ void k_fill_periodic(PBatch pb)
 {
+    const A4 &a = pb.q[blockIdx.y].a; const B3 &v = pb.q[blockIdx.y].v;
+    const int icomp = pb.q[blockIdx.y].icomp, ncomp = pb.q[blockIdx.y].ncomp;
+    const int perx = pb.perx, pery = pb.pery, lenx = pb.lenx, leny = pb.leny;
     const int NX = a.hi0 - a.lo0 + 1, NY = a.hi1 - a.lo1 + 1;
     const int vx = v.hi0 - v.lo0 + 1, vy = v.hi1 - v.lo1 + 1;
     const int nglo_x = v.lo0 - a.lo0, nglo_y = v.lo1 - a.lo1;
@@ -197,6 +204,15 @@ static int halo_fill_list(rh_ctx *c, const std::vector<HaloItem> &items)
     const int lenx = c->dom.hi[0] - c->dom.lo[0] + 1, leny = c->dom.hi[1] - c->dom.lo[1] + 1;
     // a direction wraps locally when one rank owns all of it; the j wrap of an i-decomposed run waits for phase X (it carries ghost columns)
     const int perx = (npx == 1) ? c->prm.periodic[0] : 0, pery = (npy == 1 && npx == 1) ? c->prm.periodic[1] : 0;
+    PBatch pb; pb.n = 0; pb.perx = perx; pb.pery = pery; pb.lenx = lenx; pb.leny = leny;
+    long pbig = 0;
+    auto pgo = [&]() -> int {
+        if (!pb.n) return 0;
+        long nb = (pbig + 255) / 256; if (nb > 4096) nb = 4096;
+        k_fill_periodic<<<dim3((unsigned)nb, (unsigned)pb.n, 1), 256, 0, c->stream>>>(pb);
+        pb.n = 0; pbig = 0;
+        RH_LAUNCH_CHECK(); return 0;
+    };
     for (const HaloItem &it : items) {
         const A4 a = mkA(it.m.a); const B3 v = mkB(it.m.valid);
         const long NX = a.hi0 - a.lo0 + 1, NY = a.hi1 - a.lo1 + 1, vx = v.hi0 - v.lo0 + 1, vy = v.hi1 - v.lo1 + 1;
@@ -204,12 +220,13 @@ static int halo_fill_list(rh_ctx *c, const std::vector<HaloItem> &items)
         if (perx || pery) {
             const long total = ((NY - vy) * NX + vy * (NX - vx)) * (a.hi2 - a.lo2 + 1) * it.ncomp;
             if (total > 0) {
-                long nb = (total + 255) / 256; if (nb > 4096) nb = 4096;
-                k_fill_periodic<<<(int)nb, 256, 0, c->stream>>>(a, v, it.icomp, it.ncomp, perx, pery, lenx, leny);
-                RH_LAUNCH_CHECK();
+                PFill &f = pb.q[pb.n++]; f.a = a; f.v = v; f.icomp = it.icomp; f.ncomp = it.ncomp;
+                pbig = std::max(pbig, total);
+                if (pb.n == P_BATCH) RH_TRY(pgo());
             }
         }
     }
+    RH_TRY(pgo());
     if (npx == 1 && npy == 1) return 0;
     if (npx > 1) RH_TRY(exchange_phase(c, items, 0));
     if (npy > 1) RH_TRY(exchange_phase(c, items, 1));
@@ -226,6 +243,45 @@ static int halo_fill_list(rh_ctx *c, const std::vector<HaloItem> &items)
             RH_LAUNCH_CHECK();
         }
     }
+    return 0;
+}
+
+// ---- side stream ------------------------------------------------------------------------------------------------
+// The scope swaps the context's stream and message slots, so every launch and every message of the fills inside it goes to the
+// side stream; one communicator serves both streams, its operations kept in issue order by an event (comm_exchange).
+static void async_swap(rh_ctx *c)
+{
+    std::swap(c->stream, c->xstream); std::swap(c->d_xbuf, c->d_xbuf2); std::swap(c->xcap, c->xcap2);
+}
+int halo_async_begin(rh_ctx *c)
+{
+    if (c->no_async || c->async_on) return 0;
+    RH_TRY(bc_flush(c));
+    RH_TRY(halo_async_join(c));                          // one scope in flight at a time
+    if (!c->xstream) {
+        RH_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+        RH_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); RH_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    RH_HIP(hipEventRecord(c->ev_fork, c->stream));
+    RH_HIP(hipStreamWaitEvent(c->xstream, c->ev_fork, 0));
+    async_swap(c); c->async_on = true;
+    return 0;
+}
+int halo_async_end(rh_ctx *c)
+{
+    if (!c->async_on) return 0;
+    const int rc = bc_flush(c);
+    hipError_t e = hipEventRecord(c->ev_join, c->stream);           // c->stream is the side stream here
+    async_swap(c); c->async_on = false; c->async_pending = true;
+    if (rc) return rc;
+    RH_HIP(e);
+    return 0;
+}
+int halo_async_join(rh_ctx *c)
+{
+    if (!c->async_pending) return 0;
+    c->async_pending = false;
+    RH_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));
     return 0;
 }
 
