@@ -8,6 +8,11 @@
 // Arithmetic keeps the reference's operation order; the k-invariant pow() factors are formed on the host (as the reference does on
 // its host), the per-point pow() calls run on device (ocml), so parity with the CPU oracle is to rounding, not bit-exact.
 #include "rh_common.h"
+#include "rh_tile.h"
+
+// the tiled kernels' blocks (64 x 8 threads) own 63 x 7 columns: they overlap by one column and one row
+#define GH_SX (RT_BX - 1)
+#define GH_SY (RT_BY - 1)
 
 struct GlsC {
     int stab, Lmy25, N, perx, pery, dlo0, dhi0, dlo1, dhi1;
@@ -160,6 +165,101 @@ k_gls_prestep(B3 bx, A4 tke, A4 gls, A4 W, A4 Huon, A4 Hvom, A4 Hz, A4 pm, A4 pn
     }
 }
 
+// ---- the predictor with the horizontal stencils in LDS (same block shape and flux hand-over as k_gls_hadv_tiled) ----------------
+template <class Q> __device__ __forceinline__ double pre_flux_x_t(const Q &q, const A4 &msku, int i, int j, int k, double tf, const GlsC &g)
+{
+    double gm = (q(i - 1, j, k) - q(i - 2, j, k)) * msku(i - 1, j, 0);
+    double gp = (q(i + 1, j, k) - q(i, j, k)) * msku(i + 1, j, 0);
+    if (i == g.dlo0 - 1 && !g.perx) gm = q(i, j, k) - q(i - 1, j, k);
+    else if (i == g.dhi0 + 1 && !g.perx) gp = q(i, j, k) - q(i - 1, j, k);
+    const double cff = 1.0 / 6.0;
+    return tf * 0.5 * (q(i - 1, j, k) + q(i, j, k) - cff * (gp - gm));
+}
+template <class Q> __device__ __forceinline__ double pre_flux_y_t(const Q &q, const A4 &mskv, int i, int j, int k, double tf, const GlsC &g)
+{
+    double gm = (q(i, j - 1, k) - q(i, j - 2, k)) * mskv(i, j - 1, 0);
+    double gp = (q(i, j + 1, k) - q(i, j, k)) * mskv(i, j + 1, 0);
+    if (j == g.dlo1 - 1 && !g.pery) gm = q(i, j, k) - q(i, j - 1, k);
+    else if (j == g.dhi1 + 1 && !g.pery) gp = q(i, j, k) - q(i, j - 1, k);
+    const double cff = 1.0 / 6.0;
+    return tf * 0.5 * (q(i, j - 1, k) + q(i, j, k) - cff * (gp - gm));
+}
+// vertical flux through rho-level k from the column window (qm, q0, q1, q2) = q(k-1), q(k), q(k+1), q(k+2)
+__device__ __forceinline__ double vert_flux_w(int k, int N, double cf, double qm, double q0, double q1, double q2)
+{
+    if (k == N) { const double a = 1.0 / 3.0, b = 5.0 / 6.0, c = 1.0 / 6.0; return cf * (a * q1 + b * q0 - c * qm); }
+    const double a = 7.0 / 12.0, b = 1.0 / 12.0;
+    return cf * (a * (q0 + q1) - b * (qm + q2));
+}
+__global__ void __launch_bounds__(RT_BX * RT_BY)
+k_gls_prestep_tiled(B3 bx, A4 tks, A4 gss, A4 tki, A4 gsi, A4 tk2, A4 gs2, A4 tkn, A4 gsn, A4 W, A4 Huon, A4 Hvom, A4 Hz, A4 pm, A4 pn,
+                    A4 msku, A4 mskv, double cff1, double cff2, double cff3, GlsC g)
+{   // tks / gss: time level nstp; tki / gsi: level indx; tk2 / gs2: predictor (component 2); tkn / gsn: level nnew
+    typedef Tile<2, 2> T;
+    constexpr int NT = RT_BX * RT_BY;
+    __shared__ double lds[4 * T::SIZE + 6 * NT];
+    double *fl = lds + 4 * T::SIZE;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
+    const RhTile rt = rh_tile_patch<1, 4>();
+    const int I0 = bx.lo0 + rt.x * GH_SX, J0 = bx.lo1 + rt.y * GH_SY, i = I0 + tx, j = J0 + ty;
+    const bool owner = tx < GH_SX && ty < GH_SY && i <= bx.hi0 && j <= bx.hi1;
+    const bool fx_on = i <= bx.hi0 + 1 && j <= bx.hi1, fy_on = i <= bx.hi0 && j <= bx.hi1 + 1;
+    const HaloCell hc = halo_cell<2, 2>(tks, I0, J0, tx, ty);
+    const int N = g.N;
+    const double cff4 = owner ? cff3 * pm(i, j, 0) * pn(i, j, 0) : 0.0;
+    // column windows of the own point: levels k-1 .. k+2 (k = 1 first), the level after them in flight
+    double tm = ld_in(tks, i, j, 0), t0 = ld_in(tks, i, j, 1), t1 = ld_in(tks, i, j, 2), t2 = N >= 2 ? ld_in(tks, i, j, 3) : 0.0;
+    double gm = ld_in(gss, i, j, 0), g0 = ld_in(gss, i, j, 1), g1 = ld_in(gss, i, j, 2), g2 = N >= 2 ? ld_in(gss, i, j, 3) : 0.0;
+    double t_h = halo_ld(tks, hc, 1), g_h = halo_ld(gss, hc, 1);
+    double hu_m = fx_on ? Huon(i, j, 0) : 0.0, hv_m = fy_on ? Hvom(i, j, 0) : 0.0, hu = fx_on ? Huon(i, j, 1) : 0.0, hv = fy_on ? Hvom(i, j, 1) : 0.0;
+    double hz_m = 0.0, hz = 0.0, w_k = 0.0, w_p = 0.0, ti = 0.0, gi = 0.0, cf_m = 0.0, fc_m = 0.0, fl_m = 0.0;
+    if (owner) {
+        hz_m = Hz(i, j, 0); hz = Hz(i, j, 1); w_k = W(i, j, 1); w_p = W(i, j, 2); ti = tki(i, j, 1); gi = gsi(i, j, 1);
+        cf_m = 0.5 * (w_k + W(i, j, 0));                                        // rho-level 0 (:165-174)
+        const double a = 1.0 / 3.0, b = 5.0 / 6.0, c = 1.0 / 6.0;
+        fc_m = cf_m * (a * tm + b * t0 - c * t1); fl_m = cf_m * (a * gm + b * g0 - c * g1);
+    }
+    for (int k = 1; k <= N; k++) {
+        double *bt = lds + (k & 1) * 2 * T::SIZE, *bg = bt + T::SIZE;
+        tile_put<2, 2>(bt, tx, ty, t0, hc, t_h); tile_put<2, 2>(bg, tx, ty, g0, hc, g_h);
+        const double hu_c = hu, hv_c = hv, hz_c = hz, ti_c = ti, gi_c = gi, w_c = w_k, w_n = w_p;
+        double t3 = 0.0, g3 = 0.0;
+        if (k < N) {                                                             // next level's operands
+            if (k + 3 <= N + 1) { t3 = ld_in(tks, i, j, k + 3); g3 = ld_in(gss, i, j, k + 3); }
+            t_h = halo_ld(tks, hc, k + 1); g_h = halo_ld(gss, hc, k + 1);
+            if (fx_on) hu = Huon(i, j, k + 1);
+            if (fy_on) hv = Hvom(i, j, k + 1);
+            if (owner) { hz = Hz(i, j, k + 1); w_p = W(i, j, k + 2); ti = tki(i, j, k + 1); gi = gsi(i, j, k + 1); }
+        }
+        __syncthreads();
+        const TView<2, 2> vt{bt, I0, J0}, vg{bg, I0, J0};
+        double xf = 0.0, ef = 0.0, fx = 0.0, fe = 0.0, lx = 0.0, le = 0.0;
+        if (fx_on) { xf = 0.5 * (hu_c + hu_m); fx = pre_flux_x_t(vt, msku, i, j, k, xf, g); lx = pre_flux_x_t(vg, msku, i, j, k, xf, g); }
+        if (fy_on) { ef = 0.5 * (hv_c + hv_m); fe = pre_flux_y_t(vt, mskv, i, j, k, ef, g); le = pre_flux_y_t(vg, mskv, i, j, k, ef, g); }
+        fl[tid] = xf; fl[NT + tid] = fx; fl[2 * NT + tid] = lx; fl[3 * NT + tid] = ef; fl[4 * NT + tid] = fe; fl[5 * NT + tid] = le;
+        __syncthreads();
+        if (owner) {
+            const double xf1 = fl[tid + 1], fx1 = fl[NT + tid + 1], lx1 = fl[2 * NT + tid + 1];
+            const double ef1 = fl[3 * NT + tid + RT_BX], fe1 = fl[4 * NT + tid + RT_BX], le1 = fl[5 * NT + tid + RT_BX];
+            const double cff = 0.5 * (hz_c + hz_m);
+            double hzh = cff - cff4 * (xf1 - xf + ef1 - ef);
+            double p2 = cff * (cff1 * t0 + cff2 * ti_c) - cff4 * (fx1 - fx + fe1 - fe);
+            double q2 = cff * (cff1 * g0 + cff2 * gi_c) - cff4 * (lx1 - lx + le1 - le);
+            const double cf_k = 0.5 * (w_n + w_c);
+            const double fc_k = vert_flux_w(k, N, cf_k, tm, t0, t1, t2), fl_k = vert_flux_w(k, N, cf_k, gm, g0, g1, g2);
+            hzh = hzh - cff4 * (cf_k - cf_m);
+            const double inv = 1.0 / hzh;
+            p2 = inv * (p2 - cff4 * (fc_k - fc_m));
+            q2 = inv * (q2 - cff4 * (fl_k - fl_m));
+            tk2(i, j, k) = p2; gs2(i, j, k) = q2;
+            tkn(i, j, k) = cff * t0; gsn(i, j, k) = cff * g0;
+            cf_m = cf_k; fc_m = fc_k; fl_m = fl_k;
+        }
+        hu_m = hu_c; hv_m = hv_c; hz_m = hz_c; w_k = w_n;
+        tm = t0; t0 = t1; t1 = t2; t2 = t3; gm = g0; g0 = g1; g1 = g2; g2 = g3;
+    }
+}
+
 extern "C" int rh_gls_prestep(rh_ctx *c, rh_state *s, rh_array4 W, int nstp, int nnew, int iic, int ntfirst)
 {
     TScope t(c, "gls_prestep");
@@ -177,8 +277,15 @@ extern "C" int rh_gls_prestep(rh_ctx *c, rh_state *s, rh_array4 W, int nstp, int
     if (iic == ntfirst) { cff1 = 1.0; cff2 = 0.0; cff3 = 0.5 * dt; indx = nstp; }
     else { cff1 = 0.5 + gamma; cff2 = 0.5 - gamma; cff3 = (1.0 - gamma) * dt; indx = 1 - nstp; }
     const GlsC g = gls_constants(c);
-    k_gls_prestep<<<grid2(bx), rh_block(), 0, c->stream>>>(mkB(bx), mkA(s->tke), mkA(s->gls), mkA(W), mkA(s->Huon), mkA(s->Hvom), mkA(s->Hz),
-        mkA(s->pm), mkA(s->pn), mkA(s->msku), mkA(s->mskv), nstp, nnew, indx, cff1, cff2, cff3, g);
+    if (c->unfused || c->N < 2)
+        k_gls_prestep<<<grid2(bx), rh_block(), 0, c->stream>>>(mkB(bx), mkA(s->tke), mkA(s->gls), mkA(W), mkA(s->Huon), mkA(s->Hvom), mkA(s->Hz),
+            mkA(s->pm), mkA(s->pn), mkA(s->msku), mkA(s->mskv), nstp, nnew, indx, cff1, cff2, cff3, g);
+    else {
+        const dim3 grid((bx.hi[0] - bx.lo[0] + GH_SX) / GH_SX, (bx.hi[1] - bx.lo[1] + GH_SY) / GH_SY, 1);
+        k_gls_prestep_tiled<<<grid, rt_block(), 0, c->stream>>>(mkB(bx), mkA(s->tke, nstp), mkA(s->gls, nstp), mkA(s->tke, indx), mkA(s->gls, indx),
+            mkA(s->tke, 2), mkA(s->gls, 2), mkA(s->tke, nnew), mkA(s->gls, nnew), mkA(W), mkA(s->Huon), mkA(s->Hvom), mkA(s->Hz),
+            mkA(s->pm), mkA(s->pn), mkA(s->msku), mkA(s->mskv), cff1, cff2, cff3, g);
+    }
     RH_LAUNCH_CHECK();
     BcScope bcs(c);                                                               // :212-215
     for (int ic = 0; ic < 3; ic++) {
@@ -265,6 +372,84 @@ __global__ void k_gls_hadv(B3 b, A4 tke, A4 gls, A4 Huon, A4 Hvom, A4 pm, A4 pn,
     tke(i, j, k, nnew) = dmax_(t, g.Kmin);
     double p = gls(i, j, k, nnew) - cff * (fxp[1] - fxp[0] + fep[1] - fep[0]);
     gls(i, j, k, nnew) = dmax_(p, g.Pmin);
+}
+
+// The same pass with the predictor staged in LDS: one 64 x 8 block marches k over a 63 x 7 patch of columns (blocks overlap by one
+// column and one row, so the flux through a patch's last faces is computed by the threads that sit on them and no flux is formed
+// twice from global memory).  Per level: tke and gls (component 2) go into halo-2 tiles, double-buffered on the parity of k, with
+// the next level's values already in flight; every thread forms the x-flux through its west face and the y-flux through its south
+// face from the tiles and leaves them in LDS for its east / north neighbour.  Huon / Hvom are read once per level (the level below
+// is carried).  Same expressions as k_gls_hadv: bit-identical.
+template <class Q> __device__ __forceinline__ double curv_x_t(const Q &q, const A4 &msku, int i, int j, int k, const GlsC &g)
+{
+    double gr, gr1;
+    if (i == g.dlo0 - 1 && !g.perx) { gr1 = q(i + 1, j, k) - q(i, j, k); gr = gr1; }
+    else if (i == g.dhi0 + 1 && !g.perx) { gr = q(i, j, k) - q(i - 1, j, k); gr1 = gr; }
+    else { gr = (q(i, j, k) - q(i - 1, j, k)) * msku(i, j, 0); gr1 = (q(i + 1, j, k) - q(i, j, k)) * msku(i + 1, j, 0); }
+    return gr1 - gr;
+}
+template <class Q> __device__ __forceinline__ double curv_y_t(const Q &q, const A4 &mskv, int i, int j, int k, const GlsC &g)
+{
+    double gr = (q(i, j, k) - q(i, j - 1, k)) * mskv(i, j, 0);
+    double gr1 = (q(i, j + 1, k) - q(i, j, k)) * mskv(i, j + 1, 0);
+    if (j == g.dlo1 - 1 && !g.pery) gr = gr1;
+    else if (j == g.dhi1 + 1 && !g.pery) gr1 = gr;
+    return gr1 - gr;
+}
+__global__ void __launch_bounds__(RT_BX * RT_BY)
+k_gls_hadv_tiled(B3 b, A4 tke2, A4 gls2, A4 tkn, A4 gln, A4 Huon, A4 Hvom, A4 pm, A4 pn, A4 msku, A4 mskv, double dt, GlsC g)
+{
+    typedef Tile<2, 2> T;
+    constexpr int NT = RT_BX * RT_BY;
+    __shared__ double lds[4 * T::SIZE + 4 * NT];
+    double *fl = lds + 4 * T::SIZE;
+    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
+    const RhTile rt = rh_tile_patch<1, 4>();
+    const int I0 = b.lo0 + rt.x * GH_SX, J0 = b.lo1 + rt.y * GH_SY, i = I0 + tx, j = J0 + ty;
+    const bool owner = tx < GH_SX && ty < GH_SY && i <= b.hi0 && j <= b.hi1;
+    const bool fx_on = i <= b.hi0 + 1 && j <= b.hi1, fy_on = i <= b.hi0 && j <= b.hi1 + 1;
+    const HaloCell hc = halo_cell<2, 2>(tke2, I0, J0, tx, ty);
+    const int k0 = b.lo2, k1 = b.hi2;
+    double t_own = ld_in(tke2, i, j, k0), g_own = ld_in(gls2, i, j, k0), t_h = halo_ld(tke2, hc, k0), g_h = halo_ld(gls2, hc, k0);
+    double hu_m = fx_on ? Huon(i, j, k0 - 1) : 0.0, hv_m = fy_on ? Hvom(i, j, k0 - 1) : 0.0;
+    double hu = fx_on ? Huon(i, j, k0) : 0.0, hv = fy_on ? Hvom(i, j, k0) : 0.0;
+    double tn = owner ? tkn(i, j, k0) : 0.0, gn = owner ? gln(i, j, k0) : 0.0;
+    const double cff = owner ? dt * pm(i, j, 0) * pn(i, j, 0) : 0.0;
+    for (int k = k0; k <= k1; k++) {
+        double *bt = lds + (k & 1) * 2 * T::SIZE, *bg = bt + T::SIZE;
+        tile_put<2, 2>(bt, tx, ty, t_own, hc, t_h); tile_put<2, 2>(bg, tx, ty, g_own, hc, g_h);
+        const double hu_c = hu, hv_c = hv, tn_c = tn, gn_c = gn;
+        if (k < k1) {                                                            // next level: in flight during this one
+            t_own = ld_in(tke2, i, j, k + 1); g_own = ld_in(gls2, i, j, k + 1); t_h = halo_ld(tke2, hc, k + 1); g_h = halo_ld(gls2, hc, k + 1);
+            if (fx_on) hu = Huon(i, j, k + 1);
+            if (fy_on) hv = Hvom(i, j, k + 1);
+            if (owner) { tn = tkn(i, j, k + 1); gn = gln(i, j, k + 1); }
+        }
+        __syncthreads();
+        const TView<2, 2> vt{bt, I0, J0}, vg{bg, I0, J0};
+        double fxk = 0.0, fxp = 0.0, fek = 0.0, fep = 0.0;
+        if (fx_on) {
+            const double cx = 0.5 * (hu_c + hu_m);
+            const int iu = (cx > 0.0) ? i - 1 : i;
+            fxk = cx * 0.5 * (vt(i - 1, j, k) + vt(i, j, k) - g.Gadv * curv_x_t(vt, msku, iu, j, k, g));
+            fxp = cx * 0.5 * (vg(i - 1, j, k) + vg(i, j, k) - g.Gadv * curv_x_t(vg, msku, iu, j, k, g));
+        }
+        if (fy_on) {
+            const double cy = 0.5 * (hv_c + hv_m);
+            const int ju = (cy > 0.0) ? j - 1 : j;
+            fek = cy * 0.5 * (vt(i, j - 1, k) + vt(i, j, k) - g.Gadv * curv_y_t(vt, mskv, i, ju, k, g));
+            fep = cy * 0.5 * (vg(i, j - 1, k) + vg(i, j, k) - g.Gadv * curv_y_t(vg, mskv, i, ju, k, g));
+        }
+        fl[tid] = fxk; fl[NT + tid] = fxp; fl[2 * NT + tid] = fek; fl[3 * NT + tid] = fep;
+        __syncthreads();
+        if (owner) {
+            const double t = tn_c - cff * (fl[tid + 1] - fxk + fl[2 * NT + tid + RT_BX] - fek);
+            tkn(i, j, k) = dmax_(t, g.Kmin);
+            const double p = gn_c - cff * (fl[NT + tid + 1] - fxp + fl[3 * NT + tid + RT_BX] - fep);
+            gln(i, j, k) = dmax_(p, g.Pmin);
+        }
+        hu_m = hu_c; hv_m = hv_c;
+    }
 }
 
 // One thread per column (:620-902): vertical advection, production / dissipation and the forward elimination for tke top-down;
@@ -437,8 +622,14 @@ extern "C" int rh_gls_corrector(rh_ctx *c, rh_state *s, rh_array4 W, int nstp, i
     RH_TRY(halo_physbc(c, mfv(c, c->gS2C, 0, 0, 0), s->mskr, 0, 1, RH_BCV_FOEXTRAP, 0));
     k_gls_avg<<<grid3(win), rh_block(), 0, c->stream>>>(mkB(win), mkA(s->bvf), mkA(c->gS2C), mkA(c->gB2), mkA(c->gS2));
     RH_LAUNCH_CHECK();
-    k_gls_hadv<<<grid3(win), rh_block(), 0, c->stream>>>(mkB(win), mkA(s->tke), mkA(s->gls), mkA(s->Huon), mkA(s->Hvom), mkA(s->pm), mkA(s->pn),
-                                                         mkA(s->msku), mkA(s->mskv), nnew, dt, g);
+    if (c->unfused)
+        k_gls_hadv<<<grid3(win), rh_block(), 0, c->stream>>>(mkB(win), mkA(s->tke), mkA(s->gls), mkA(s->Huon), mkA(s->Hvom), mkA(s->pm), mkA(s->pn),
+                                                             mkA(s->msku), mkA(s->mskv), nnew, dt, g);
+    else {
+        const dim3 grid((bx.hi[0] - bx.lo[0] + GH_SX) / GH_SX, (bx.hi[1] - bx.lo[1] + GH_SY) / GH_SY, 1);
+        k_gls_hadv_tiled<<<grid, rt_block(), 0, c->stream>>>(mkB(win), mkA(s->tke, 2), mkA(s->gls, 2), mkA(s->tke, nnew), mkA(s->gls, nnew),
+                                                             mkA(s->Huon), mkA(s->Hvom), mkA(s->pm), mkA(s->pn), mkA(s->msku), mkA(s->mskv), dt, g);
+    }
     RH_LAUNCH_CHECK();
     k_gls_column<<<grid2(bx), rh_block(), 0, c->stream>>>(mkB(bx), mkA(s->tke), mkA(s->gls), mkA(W), mkA(s->Akv), mkA(s->Akt), mkA(s->Akk), mkA(s->Akp),
         mkA(s->Lscale), mkA(s->Hz), mkA(s->pm), mkA(s->pn), mkA(s->z_w), mkA(s->sustr), mkA(s->svstr), mkA(s->bustr), mkA(s->bvstr),

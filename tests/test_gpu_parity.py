@@ -85,7 +85,7 @@ def test_gls_phases_against_oracle(case, libm_pow, monkeypatch):
     rem.close(); orc.close()
 
 
-@pytest.mark.parametrize("case", ["Seamount", "Advection"])
+@pytest.mark.parametrize("case", ["Seamount", "Advection", "Upwelling_GLS"])
 def test_leaf_entry_points_against_oracle(case, monkeypatch):
     """RH_UNFUSED=1 makes the drivers go through the per-leaf C entry points (rh_prestep_t, rh_t3dmix, rh_rhs_t_3d, ...) instead
     of the fused multi-tracer kernels: both routes must agree with the oracle (and hence with each other)."""
@@ -95,7 +95,7 @@ def test_leaf_entry_points_against_oracle(case, monkeypatch):
     upload_oracle_state(orc, rem)
     for step in range(3):
         orc.advance(1); rem.timeStep()
-        _check(compare_states(orc, rem), case, f"unfused step {step}")
+        _check(compare_states(orc, rem, COMPARE + (GLS_FIELDS if "gls" in cfg else [])), case, f"unfused step {step}")
     rem.close(); orc.close()
 
 
