@@ -326,13 +326,36 @@ enum { T_D, T_U, T_V, T_UB, T_VB, T_PM, T_PN, T_N };      // tiles: Drhs, DUon, 
 // One memory round trip per block: every global load of the kernel -- the tile points (two per thread) and this thread's own
 // operands of all later phases -- is issued up front; plain loads stay in flight across the barriers, so the LDS phases run
 // while the late operands are still arriving.  All stencil neighbours (ubar, vbar, pm, pn, Drhs, DUon, DVom) come from LDS.
+// The kernel touches ~40 arrays; as amrex-style views (base + 3-D box + strides each) their descriptors alone need ~480 scalar
+// registers, and the compiler spilled them to vector lanes: 38 % of the vector instructions of the first version were
+// v_readlane / v_writelane of spilled scalars.  The arrays come in four shapes only -- rho points with 3 or with 2 ghost cells, u
+// faces, v faces -- so the kernel takes ONE shape per group plus bare pointers; equal shapes also share their index arithmetic.
+struct S2 { int lo0, lo1, hi0, hi1; unsigned sy; };
+struct V2 {
+    const S2 &s; double *p;
+    __device__ __forceinline__ double &operator()(int i, int j, int) const { return p[(unsigned)(i - s.lo0) + (unsigned)(j - s.lo1) * s.sy]; }
+};
+__device__ __forceinline__ double ld_in(const V2 &a, int i, int j, int)
+{ return (i >= a.s.lo0 && i <= a.s.hi0 && j >= a.s.lo1 && j <= a.s.hi1) ? a(i, j, 0) : 0.0; }
+enum { R3_ZRHS, R3_ZSTP, R3_ZNEW, R3_H, R3_FCOR, R3_MSKR, R3_ZT, R3_N };                       // rho points, 3 ghost cells
+enum { R2_RZSTP, R2_RZPTS, R2_RZRHS, R2_RHOS, R2_RHOA, R2_VR, R2_VP, R2_N };                   // rho points, 2 ghost cells
+enum { FA_RHS, FA_STP, FA_NEW, FA_RRHS, FA_RSTP, FA_RPTS, FA_FRC, FA_R2D0, FA_R2D1, FA_AVG1, FA_AVG2, FA_DON, FA_N };   // per face direction
+struct K2Arrays { S2 r3, r2, u2, v2; double *R3[R3_N], *R2[R2_N], *U[FA_N], *V[FA_N]; A4 pm, pn, msku, mskv, mskp; };
 __global__ void __launch_bounds__(RT_BX * U_BY)
-k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, A4 ub_rhs, A4 vb_rhs, A4 ub_stp, A4 vb_stp, A4 ub_new, A4 vb_new,
-          A4 rubar_rhs, A4 rvbar_rhs, A4 rubar_stp, A4 rvbar_stp, A4 rubar_pts, A4 rvbar_pts,
-          A4 zeta_rhs, A4 zeta_stp, A4 zeta_new, A4 rzeta_stp, A4 rzeta_pts, A4 rzeta_rhs,
-          A4 h, A4 pm, A4 pn, A4 fcor, A4 rhoS, A4 rhoA, A4 mskr, A4 msku, A4 mskv, A4 mskp, A4 visc2_p, A4 visc2_r,
-          A4 rufrc, A4 rvfrc, A4 ru2d, A4 rv2d, A4 Zt_avg1, A4 DU_avg1, A4 DU_avg2, A4 DV_avg1, A4 DV_avg2, A4 DUon_g, A4 DVom_g, int ghost_from_mem)
+k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, K2Arrays A, int ghost_from_mem)
 {
+    const V2 ub_rhs{A.u2, A.U[FA_RHS]}, ub_stp{A.u2, A.U[FA_STP]}, ub_new{A.u2, A.U[FA_NEW]}, rubar_rhs{A.u2, A.U[FA_RRHS]}, rubar_stp{A.u2, A.U[FA_RSTP]},
+             rubar_pts{A.u2, A.U[FA_RPTS]}, rufrc{A.u2, A.U[FA_FRC]}, ru2d0{A.u2, A.U[FA_R2D0]}, ru2d1{A.u2, A.U[FA_R2D1]}, DU_avg1{A.u2, A.U[FA_AVG1]},
+             DU_avg2{A.u2, A.U[FA_AVG2]}, DUon_g{A.u2, A.U[FA_DON]};
+    const V2 vb_rhs{A.v2, A.V[FA_RHS]}, vb_stp{A.v2, A.V[FA_STP]}, vb_new{A.v2, A.V[FA_NEW]}, rvbar_rhs{A.v2, A.V[FA_RRHS]}, rvbar_stp{A.v2, A.V[FA_RSTP]},
+             rvbar_pts{A.v2, A.V[FA_RPTS]}, rvfrc{A.v2, A.V[FA_FRC]}, rv2d0{A.v2, A.V[FA_R2D0]}, rv2d1{A.v2, A.V[FA_R2D1]}, DV_avg1{A.v2, A.V[FA_AVG1]},
+             DV_avg2{A.v2, A.V[FA_AVG2]}, DVom_g{A.v2, A.V[FA_DON]};
+    const V2 zeta_rhs{A.r3, A.R3[R3_ZRHS]}, zeta_stp{A.r3, A.R3[R3_ZSTP]}, zeta_new{A.r3, A.R3[R3_ZNEW]}, h{A.r3, A.R3[R3_H]}, fcor{A.r3, A.R3[R3_FCOR]},
+             mskr{A.r3, A.R3[R3_MSKR]}, Zt_avg1{A.r3, A.R3[R3_ZT]};
+    const V2 rzeta_stp{A.r2, A.R2[R2_RZSTP]}, rzeta_pts{A.r2, A.R2[R2_RZPTS]}, rzeta_rhs{A.r2, A.R2[R2_RZRHS]}, rhoS{A.r2, A.R2[R2_RHOS]},
+             rhoA{A.r2, A.R2[R2_RHOA]}, visc2_r{A.r2, A.R2[R2_VR]}, visc2_p{A.r2, A.R2[R2_VP]};
+    const A4 &pm = A.pm, &pn = A.pn, &msku = A.msku, &mskv = A.mskv, &mskp = A.mskp;
+
     constexpr int NT = RT_BX * U_BY;
     __shared__ double lds[QF_N * NT];
     static_assert(T_N * F_N <= QF_N * NT, "tiles alias the flux slots");
@@ -379,16 +402,16 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
     double u_frc = 0, u_r0 = 0, u_r1 = 0, u_stp = 0, u_rs = 0, u_rp = 0, u_msk = 1.0, u_zsw = 0;
     if (is_u) {
         u_frc = rufrc(i, j, 0); u_stp = ub_stp(i, j, 0); u_zsw = zeta_stp(i - 1, j, 0);
-        if (P.couple >= 2) u_r0 = ru2d(i, j, 0, 0);
-        if (P.couple == 3) u_r1 = ru2d(i, j, 0, 1);
+        if (P.couple >= 2) u_r0 = ru2d0(i, j, 0);
+        if (P.couple == 3) u_r1 = ru2d1(i, j, 0);
         if (P.am3) { u_rs = rubar_stp(i, j, 0); u_rp = rubar_pts(i, j, 0); }
         if (!P.nomask) u_msk = msku(i, j, 0);
     }
     double v_frc = 0, v_r0 = 0, v_r1 = 0, v_stp = 0, v_rs = 0, v_rp = 0, v_msk = 1.0, v_zss = 0;
     if (is_v) {
         v_frc = rvfrc(i, j, 0); v_stp = vb_stp(i, j, 0); v_zss = zeta_stp(i, j - 1, 0);
-        if (P.couple >= 2) v_r0 = rv2d(i, j, 0, 0);
-        if (P.couple == 3) v_r1 = rv2d(i, j, 0, 1);
+        if (P.couple >= 2) v_r0 = rv2d0(i, j, 0);
+        if (P.couple == 3) v_r1 = rv2d1(i, j, 0);
         if (P.am3) { v_rs = rvbar_stp(i, j, 0); v_rp = rvbar_pts(i, j, 0); }
         if (!P.nomask) v_msk = mskv(i, j, 0);
     }
@@ -528,18 +551,18 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
         if (P.couple == 0) rhs += u_frc;
         else {
             double f = u_frc;
-            if (P.couple == 1) { f -= rhs; rhs += f; ru2d(i, j, 0, 0) = f; }
+            if (P.couple == 1) { f -= rhs; rhs += f; ru2d0(i, j, 0) = f; }
             else if (P.couple == 2) {
                 f = f - rhs;
                 const double r0 = u_r0;
                 rhs = rhs + 1.5 * f - 0.5 * r0;
-                ru2d(i, j, 0, 1) = r0; ru2d(i, j, 0, 0) = f;
+                ru2d1(i, j, 0) = r0; ru2d0(i, j, 0) = f;
             } else {
                 const double c1 = 23.0 / 12.0, c2 = 16.0 / 12.0, c3 = 5.0 / 12.0;
                 f = f - rhs;
                 const double r0 = u_r0, r1 = u_r1;
                 rhs = rhs + c1 * f - c2 * r0 + c3 * r1;
-                ru2d(i, j, 0, 1) = r0; ru2d(i, j, 0, 0) = f;
+                ru2d1(i, j, 0) = r0; ru2d0(i, j, 0) = f;
             }
             rufrc(i, j, 0) = f;
         }
@@ -574,18 +597,18 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
         if (P.couple == 0) rhs += v_frc;
         else {
             double f = v_frc;
-            if (P.couple == 1) { f -= rhs; rhs += f; rv2d(i, j, 0, 0) = f; }
+            if (P.couple == 1) { f -= rhs; rhs += f; rv2d0(i, j, 0) = f; }
             else if (P.couple == 2) {
                 f = f - rhs;
                 const double r0 = v_r0;
                 rhs = rhs + 1.5 * f - 0.5 * r0;
-                rv2d(i, j, 0, 1) = r0; rv2d(i, j, 0, 0) = f;
+                rv2d1(i, j, 0) = r0; rv2d0(i, j, 0) = f;
             } else {
                 const double c1 = 23.0 / 12.0, c2 = 16.0 / 12.0, c3 = 5.0 / 12.0;
                 f = f - rhs;
                 const double r0 = v_r0, r1 = v_r1;
                 rhs = rhs + c1 * f - c2 * r0 + c3 * r1;
-                rv2d(i, j, 0, 1) = r0; rv2d(i, j, 0, 0) = f;
+                rv2d1(i, j, 0) = r0; rv2d0(i, j, 0) = f;
             }
             rvfrc(i, j, 0) = f;
         }
@@ -746,7 +769,16 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
     const rh_array4 zeta_rhs = a4_comp(s->zeta, krhs), zeta_stp = a4_comp(s->zeta, kstp), zeta_new = a4_comp(s->zeta, knew);
     const rh_array4 ub_rhs = a4_comp(s->ubar, krhs), vb_rhs = a4_comp(s->vbar, krhs);
 
-    const bool fused = !c->unfused && !c->nofuse2d && my_iif < nfast;      // the last call only accumulates the averages (:362-363): three-kernel form
+    // k2d_fused takes one shape per group of arrays (see K2Arrays): native states and REMORA's MultiFabs have them by construction
+    auto same2 = [](std::initializer_list<const rh_array4 *> l) {
+        const rh_array4 *f = *l.begin();
+        for (const rh_array4 *a : l) if (a->lo[0] != f->lo[0] || a->lo[1] != f->lo[1] || a->hi[0] != f->hi[0] || a->hi[1] != f->hi[1] || a->lo[2] != 0) return false;
+        return true;
+    };
+    const bool shapes_ok = same2({&s->zeta, &s->h, &s->fcor, &s->mskr, &s->Zt_avg1}) && same2({&s->rzeta, &s->rhoS, &s->rhoA, &s->visc2_r, &s->visc2_p}) &&
+                           same2({&s->ubar, &s->rubar, &s->rufrc, &s->ru2d, &s->DU_avg1, &s->DU_avg2, &c->DUon}) &&
+                           same2({&s->vbar, &s->rvbar, &s->rvfrc, &s->rv2d, &s->DV_avg1, &s->DV_avg2, &c->DVom});
+    const bool fused = !c->unfused && !c->nofuse2d && my_iif < nfast && shapes_ok;   // the last call only accumulates the averages (:362-363): three-kernel form
     // ---- Drhs, DUon, DVom (:149-166) and their ghost exchange (:170-171)
     RH_NEED(s->zeta, tbxp3); RH_NEED(s->h, tbxp3);
     RH_NEED(s->ubar, xgbx2); RH_NEED(s->vbar, ygbx2); RH_NEED(c->DUon, xgbx2); RH_NEED(c->DVom, ygbx2);
@@ -817,14 +849,23 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
             k2d_frame<<<(nfr + 255) / 256, 256, 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkB(tbxp1), zp, mkA(zeta_rhs), mkA(s->h), mkA(ub_rhs), mkA(vb_rhs),
                 mkA(s->pm), mkA(s->pn), mkA(s->Zt_avg1), mkA(s->DU_avg1), mkA(s->DU_avg2), mkA(s->DV_avg1), mkA(s->DV_avg2), mkA(c->DUon), mkA(c->DVom), fb_work ? 1 : 0);
             RH_LAUNCH_CHECK();
-            k2d_fused<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), mkB(tbxp1), mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), P, zp,
-                mkA(ub_rhs), mkA(vb_rhs), mkA(a4_comp(s->ubar, kstp)), mkA(a4_comp(s->vbar, kstp)), mkA(a4_comp(s->ubar, knew)), mkA(a4_comp(s->vbar, knew)),
-                mkA(a4_comp(s->rubar, kr)), mkA(a4_comp(s->rvbar, kr)), mkA(a4_comp(s->rubar, kstp)), mkA(a4_comp(s->rvbar, kstp)),
-                mkA(a4_comp(s->rubar, ptsk)), mkA(a4_comp(s->rvbar, ptsk)),
-                mkA(zeta_rhs), mkA(zeta_stp), mkA(zeta_new), mkA(a4_comp(s->rzeta, kstp)), mkA(a4_comp(s->rzeta, ptsk)), mkA(a4_comp(s->rzeta, kr)),
-                mkA(s->h), mkA(s->pm), mkA(s->pn), mkA(s->fcor), mkA(s->rhoS), mkA(s->rhoA), mkA(s->mskr), mkA(s->msku), mkA(s->mskv), mkA(s->mskp),
-                mkA(s->visc2_p), mkA(s->visc2_r), mkA(s->rufrc), mkA(s->rvfrc), mkA(s->ru2d), mkA(s->rv2d),
-                mkA(s->Zt_avg1), mkA(s->DU_avg1), mkA(s->DU_avg2), mkA(s->DV_avg1), mkA(s->DV_avg2), mkA(c->DUon), mkA(c->DVom), fb_work ? 1 : 0);
+            K2Arrays KA; memset(&KA, 0, sizeof KA);
+            auto shape = [](const rh_array4 &a) { S2 q; q.lo0 = a.lo[0]; q.lo1 = a.lo[1]; q.hi0 = a.hi[0]; q.hi1 = a.hi[1]; q.sy = (unsigned)(a.hi[0] - a.lo[0] + 1); return q; };
+            auto comp = [](const rh_array4 &a, int n) { return mkA(a, n).p; };
+            KA.r3 = shape(s->zeta); KA.r2 = shape(s->rzeta); KA.u2 = shape(s->ubar); KA.v2 = shape(s->vbar);
+            KA.R3[R3_ZRHS] = zeta_rhs.p; KA.R3[R3_ZSTP] = zeta_stp.p; KA.R3[R3_ZNEW] = zeta_new.p; KA.R3[R3_H] = s->h.p; KA.R3[R3_FCOR] = s->fcor.p;
+            KA.R3[R3_MSKR] = s->mskr.p; KA.R3[R3_ZT] = s->Zt_avg1.p;
+            KA.R2[R2_RZSTP] = comp(s->rzeta, kstp); KA.R2[R2_RZPTS] = comp(s->rzeta, ptsk); KA.R2[R2_RZRHS] = comp(s->rzeta, kr);
+            KA.R2[R2_RHOS] = s->rhoS.p; KA.R2[R2_RHOA] = s->rhoA.p; KA.R2[R2_VR] = s->visc2_r.p; KA.R2[R2_VP] = s->visc2_p.p;
+            KA.U[FA_RHS] = ub_rhs.p; KA.U[FA_STP] = comp(s->ubar, kstp); KA.U[FA_NEW] = comp(s->ubar, knew); KA.U[FA_RRHS] = comp(s->rubar, kr);
+            KA.U[FA_RSTP] = comp(s->rubar, kstp); KA.U[FA_RPTS] = comp(s->rubar, ptsk); KA.U[FA_FRC] = s->rufrc.p; KA.U[FA_R2D0] = comp(s->ru2d, 0);
+            KA.U[FA_R2D1] = comp(s->ru2d, 1); KA.U[FA_AVG1] = s->DU_avg1.p; KA.U[FA_AVG2] = s->DU_avg2.p; KA.U[FA_DON] = c->DUon.p;
+            KA.V[FA_RHS] = vb_rhs.p; KA.V[FA_STP] = comp(s->vbar, kstp); KA.V[FA_NEW] = comp(s->vbar, knew); KA.V[FA_RRHS] = comp(s->rvbar, kr);
+            KA.V[FA_RSTP] = comp(s->rvbar, kstp); KA.V[FA_RPTS] = comp(s->rvbar, ptsk); KA.V[FA_FRC] = s->rvfrc.p; KA.V[FA_R2D0] = comp(s->rv2d, 0);
+            KA.V[FA_R2D1] = comp(s->rv2d, 1); KA.V[FA_AVG1] = s->DV_avg1.p; KA.V[FA_AVG2] = s->DV_avg2.p; KA.V[FA_DON] = c->DVom.p;
+            KA.pm = mkA(s->pm); KA.pn = mkA(s->pn); KA.msku = mkA(s->msku); KA.mskv = mkA(s->mskv); KA.mskp = mkA(s->mskp);
+            k2d_fused<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), mkB(tbxp1), mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), P, zp, KA,
+                                                                    fb_work ? 1 : 0);
             RH_LAUNCH_CHECK();
         } else
         k2d_uvbar<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), mkB(tbxp1), P, mkA(ub_rhs), mkA(vb_rhs),
