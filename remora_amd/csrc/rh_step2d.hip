@@ -340,10 +340,15 @@ __device__ __forceinline__ double ld_in(const V2 &a, int i, int j, int)
 enum { R3_ZRHS, R3_ZSTP, R3_ZNEW, R3_H, R3_FCOR, R3_MSKR, R3_ZT, R3_N };                       // rho points, 3 ghost cells
 enum { R2_RZSTP, R2_RZPTS, R2_RZRHS, R2_RHOS, R2_RHOA, R2_VR, R2_VP, R2_N };                   // rho points, 2 ghost cells
 enum { FA_RHS, FA_STP, FA_NEW, FA_RRHS, FA_RSTP, FA_RPTS, FA_FRC, FA_R2D0, FA_R2D1, FA_AVG1, FA_AVG2, FA_DON, FA_N };   // per face direction
-struct K2Arrays { S2 r3, r2, u2, v2; double *R3[R3_N], *R2[R2_N], *U[FA_N], *V[FA_N]; A4 pm, pn, msku, mskv, mskp; };
+struct K2Arrays { S2 r3, r2, u2, v2, spm, spn, smu, smv, smp; double *R3[R3_N], *R2[R2_N], *U[FA_N], *V[FA_N], *pm, *pn, *msku, *mskv, *mskp; };
+struct B2v { int lo0, lo1, hi0, hi1; };      // the rank's valid cell box; every box of the kernel is this one grown / made nodal
 __global__ void __launch_bounds__(RT_BX * U_BY)
-k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, K2Arrays A, int ghost_from_mem)
+k2d_fused(B2v vb, UVPar P, ZetaPar zp, K2Arrays A, int ghost_from_mem)
 {
+    // advance_2d.cpp's boxes: xbxD, ybxD, their union, tbxp1, tbxp3, xgbx2, ygbx2
+    const B3 xb{vb.lo0, vb.lo1, 0, vb.hi0 + 1, vb.hi1, 0}, yb{vb.lo0, vb.lo1, 0, vb.hi0, vb.hi1 + 1, 0}, un{vb.lo0, vb.lo1, 0, vb.hi0 + 1, vb.hi1 + 1, 0};
+    const B3 rb{vb.lo0 - 1, vb.lo1 - 1, 0, vb.hi0 + 1, vb.hi1 + 1, 0}, g3{vb.lo0 - 3, vb.lo1 - 3, 0, vb.hi0 + 3, vb.hi1 + 3, 0};
+    const B3 xg{vb.lo0 - 2, vb.lo1 - 2, 0, vb.hi0 + 3, vb.hi1 + 2, 0}, yg{vb.lo0 - 2, vb.lo1 - 2, 0, vb.hi0 + 2, vb.hi1 + 3, 0};
     const V2 ub_rhs{A.u2, A.U[FA_RHS]}, ub_stp{A.u2, A.U[FA_STP]}, ub_new{A.u2, A.U[FA_NEW]}, rubar_rhs{A.u2, A.U[FA_RRHS]}, rubar_stp{A.u2, A.U[FA_RSTP]},
              rubar_pts{A.u2, A.U[FA_RPTS]}, rufrc{A.u2, A.U[FA_FRC]}, ru2d0{A.u2, A.U[FA_R2D0]}, ru2d1{A.u2, A.U[FA_R2D1]}, DU_avg1{A.u2, A.U[FA_AVG1]},
              DU_avg2{A.u2, A.U[FA_AVG2]}, DUon_g{A.u2, A.U[FA_DON]};
@@ -354,7 +359,7 @@ k2d_fused(B3 xb, B3 yb, B3 un, B3 rb, B3 g3, B3 xg, B3 yg, UVPar P, ZetaPar zp, 
              mskr{A.r3, A.R3[R3_MSKR]}, Zt_avg1{A.r3, A.R3[R3_ZT]};
     const V2 rzeta_stp{A.r2, A.R2[R2_RZSTP]}, rzeta_pts{A.r2, A.R2[R2_RZPTS]}, rzeta_rhs{A.r2, A.R2[R2_RZRHS]}, rhoS{A.r2, A.R2[R2_RHOS]},
              rhoA{A.r2, A.R2[R2_RHOA]}, visc2_r{A.r2, A.R2[R2_VR]}, visc2_p{A.r2, A.R2[R2_VP]};
-    const A4 &pm = A.pm, &pn = A.pn, &msku = A.msku, &mskv = A.mskv, &mskp = A.mskp;
+    const V2 pm{A.spm, A.pm}, pn{A.spn, A.pn}, msku{A.smu, A.msku}, mskv{A.smv, A.mskv}, mskp{A.smp, A.mskp};
 
     constexpr int NT = RT_BX * U_BY;
     __shared__ double lds[QF_N * NT];
@@ -863,8 +868,11 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
             KA.V[FA_RHS] = vb_rhs.p; KA.V[FA_STP] = comp(s->vbar, kstp); KA.V[FA_NEW] = comp(s->vbar, knew); KA.V[FA_RRHS] = comp(s->rvbar, kr);
             KA.V[FA_RSTP] = comp(s->rvbar, kstp); KA.V[FA_RPTS] = comp(s->rvbar, ptsk); KA.V[FA_FRC] = s->rvfrc.p; KA.V[FA_R2D0] = comp(s->rv2d, 0);
             KA.V[FA_R2D1] = comp(s->rv2d, 1); KA.V[FA_AVG1] = s->DV_avg1.p; KA.V[FA_AVG2] = s->DV_avg2.p; KA.V[FA_DON] = c->DVom.p;
-            KA.pm = mkA(s->pm); KA.pn = mkA(s->pn); KA.msku = mkA(s->msku); KA.mskv = mkA(s->mskv); KA.mskp = mkA(s->mskp);
-            k2d_fused<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), mkB(tbxp1), mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), P, zp, KA,
+            KA.spm = shape(s->pm); KA.spn = shape(s->pn); KA.smu = shape(s->msku); KA.smv = shape(s->mskv); KA.smp = shape(s->mskp);
+            KA.pm = s->pm.p; KA.pn = s->pn.p; KA.msku = s->msku.p; KA.mskv = s->mskv.p; KA.mskp = s->mskp.p;
+            if (s->pm.lo[2] != 0 || s->pn.lo[2] != 0 || s->msku.lo[2] != 0 || s->mskv.lo[2] != 0 || s->mskp.lo[2] != 0) return rh_fail("rh_advance_2d: 2-D arrays must sit on the k = 0 slab");
+            const B2v vbx{b2.lo[0], b2.lo[1], b2.hi[0], b2.hi[1]};
+            k2d_fused<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(vbx, P, zp, KA,
                                                                     fb_work ? 1 : 0);
             RH_LAUNCH_CHECK();
         } else
