@@ -905,13 +905,16 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
     double frcu = au ? rufrc(i, j, 0) : 0.0, frcv = av ? rvfrc(i, j, 0) : 0.0;
     const HaloCell hu = halo_cell<2, 2>(uold, i0, j0, tx, ty), hv = halo_cell<2, 2>(vold, i0, j0, tx, ty), hHu = halo_cell<2, 2>(Huon, i0, j0, tx, ty),
                    hHv = halo_cell<2, 2>(Hvom, i0, j0, tx, ty), hW = halo_cell<2, 2>(W, i0, j0, tx, ty), hHz = halo_cell<1, 1>(Hz, i0, j0, tx, ty);
+    // column cursors of the own point and of this thread's halo cell (rh_tile.h)
+    const ColPtr cu = col_ptr(uold, i, j), cv = col_ptr(vold, i, j), cHu = col_ptr(Huon, i, j), cHv = col_ptr(Hvom, i, j), cHz = col_ptr(Hz, i, j),
+                 cW = col_ptr(W, i, j), cru = au ? col_ptr(ru, i, j, nrhs) : ColPtr{nullptr, 0}, crv = av ? col_ptr(rv, i, j, nrhs) : ColPtr{nullptr, 0};
+    const ColPtr qu = halo_ptr(uold, hu), qv = halo_ptr(vold, hv), qHu = halo_ptr(Huon, hHu), qHv = halo_ptr(Hvom, hHv), qW = halo_ptr(W, hW), qHz = halo_ptr(Hz, hHz);
     // vertical windows q(k-1), q(k), q(k+1), q(k+2) of the own point
-    double um1 = 0.0, u0 = ld_in(uold, i, j, 0), up1 = ld_in(uold, i, j, 1), up2 = (2 <= N) ? ld_in(uold, i, j, 2) : 0.0;
-    double vm1 = 0.0, v0 = ld_in(vold, i, j, 0), vp1 = ld_in(vold, i, j, 1), vp2 = (2 <= N) ? ld_in(vold, i, j, 2) : 0.0;
-    double Hu0 = ld_in(Huon, i, j, 0), Hv0 = ld_in(Hvom, i, j, 0), hz = ld_in(Hz, i, j, 0), W1 = ld_in(W, i, j, 1);
-    double uh = halo_ld(uold, hu, 0), vh = halo_ld(vold, hv, 0), Huh = halo_ld(Huon, hHu, 0), Hvh = halo_ld(Hvom, hHv, 0),
-           Wh = halo_ld(W, hW, 1), hzh = halo_ld(Hz, hHz, 0);
-    double rru = au ? ru(i, j, 0, nrhs) : 0.0, rrv = av ? rv(i, j, 0, nrhs) : 0.0;
+    double um1 = 0.0, u0 = col_ld(cu, 0), up1 = col_ld(cu, 1), up2 = (2 <= N) ? col_ld(cu, 2) : 0.0;
+    double vm1 = 0.0, v0 = col_ld(cv, 0), vp1 = col_ld(cv, 1), vp2 = (2 <= N) ? col_ld(cv, 2) : 0.0;
+    double Hu0 = col_ld(cHu, 0), Hv0 = col_ld(cHv, 0), hz = col_ld(cHz, 0), W1 = col_ld(cW, 1);
+    double uh = col_ld(qu, 0), vh = col_ld(qv, 0), Huh = col_ld(qHu, 0), Hvh = col_ld(qHv, 0), Wh = col_ld(qW, 1), hzh = col_ld(qHz, 0);
+    double rru = col_ld(cru, 0), rrv = col_ld(crv, 0);
     double FCu = 0.0, FCv = 0.0;
     for (int k = 0; k <= N; k++) {
         double *set = lds + (k & 1) * SET;
@@ -921,13 +924,13 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
         tile_put<2, 2>(sW, tx, ty, W1, hW, Wh); tile_put<1, 1>(sHz, tx, ty, hz, hHz, hzh);
         // ---- prefetch level k+1
         const bool more = k + 1 <= N;
-        const double u_n = (k + 3 <= N) ? ld_in(uold, i, j, k + 3) : 0.0, v_n = (k + 3 <= N) ? ld_in(vold, i, j, k + 3) : 0.0;
-        const double Hu0_n = more ? ld_in(Huon, i, j, k + 1) : 0.0, Hv0_n = more ? ld_in(Hvom, i, j, k + 1) : 0.0, hz_n = more ? ld_in(Hz, i, j, k + 1) : 0.0;
-        const double W1_n = more ? ld_in(W, i, j, k + 2) : 0.0;
-        const double uh_n = more ? halo_ld(uold, hu, k + 1) : 0.0, vh_n = more ? halo_ld(vold, hv, k + 1) : 0.0;
-        const double Huh_n = more ? halo_ld(Huon, hHu, k + 1) : 0.0, Hvh_n = more ? halo_ld(Hvom, hHv, k + 1) : 0.0;
-        const double Wh_n = more ? halo_ld(W, hW, k + 2) : 0.0, hzh_n = more ? halo_ld(Hz, hHz, k + 1) : 0.0;
-        const double rru_n = (more && au) ? ru(i, j, k + 1, nrhs) : 0.0, rrv_n = (more && av) ? rv(i, j, k + 1, nrhs) : 0.0;
+        const double u_n = (k + 3 <= N) ? col_ld(cu, k + 3) : 0.0, v_n = (k + 3 <= N) ? col_ld(cv, k + 3) : 0.0;
+        const double Hu0_n = more ? col_ld(cHu, k + 1) : 0.0, Hv0_n = more ? col_ld(cHv, k + 1) : 0.0, hz_n = more ? col_ld(cHz, k + 1) : 0.0;
+        const double W1_n = more ? col_ld(cW, k + 2) : 0.0;
+        const double uh_n = more ? col_ld(qu, k + 1) : 0.0, vh_n = more ? col_ld(qv, k + 1) : 0.0;
+        const double Huh_n = more ? col_ld(qHu, k + 1) : 0.0, Hvh_n = more ? col_ld(qHv, k + 1) : 0.0;
+        const double Wh_n = more ? col_ld(qW, k + 2) : 0.0, hzh_n = more ? col_ld(qHz, k + 1) : 0.0;
+        const double rru_n = more ? col_ld(cru, k + 1) : 0.0, rrv_n = more ? col_ld(crv, k + 1) : 0.0;
         __syncthreads();
         const V2 tu{su, i0, j0}, tv{sv, i0, j0}, tHu{sHu, i0, j0}, tHv{sHv, i0, j0}, tW{sW, i0, j0};
         const V1 tHz{sHz, i0, j0};
@@ -945,7 +948,7 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
             const double FCk1 = win_FCw(um1, u0, up1, up2, wpart, k + 1, N, C2, w0, w1);
             const double cff = FCk1 - FCu;
             r -= cff;
-            ru(i, j, k, nrhs) = r;
+            col_st(cru, k, r);
             frcu += r;
             const double c1 = (k == N) ? inv[3 * NT] : 0.0, c2 = (k == 0) ? inv[4 * NT] : 0.0;
             frcu += c1 + c2;
@@ -965,7 +968,7 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
             const double FCk1 = win_FCw(vm1, v0, vp1, vp2, wpart, k + 1, N, C2, w0, w1);
             const double cff = FCk1 - FCv;
             r -= cff;
-            rv(i, j, k, nrhs) = r;
+            col_st(crv, k, r);
             frcv += r;
             const double c1 = (k == N) ? inv[5 * NT] : 0.0, c2 = (k == 0) ? inv[6 * NT] : 0.0;
             frcv += c1 + c2;

@@ -70,6 +70,27 @@ __device__ __forceinline__ void tile_put(double *s, int tx, int ty, double own, 
     s[(ty + HY) * Tile<HX, HY>::PX + (tx + HX)] = own;
     if (h.lds >= 0) s[h.lds] = hv;
 }
+// Column cursors.  In a k-march the (i, j) part of every own-point and halo-cell access is the same at every level, but written
+// as a(i, j, k) each access needs the array's whole descriptor (12 scalar registers per array): with 8-20 arrays in a kernel the
+// scalar file overflows and the compiler parks descriptors in vector lanes, re-reading them lane by lane inside the loop
+// (k_rhs_uv_tiled: 475 v_readlane / v_writelane before).  A cursor keeps, per thread, the address of the column's level 0 (null
+// if the point lies outside the array) and the level stride: a level is one multiply-add away and the descriptor dies after the
+// prologue.
+struct ColPtr { double *p; unsigned sz; };
+__device__ __forceinline__ ColPtr col_ptr(const A4 &a, int i, int j, int n = 0)
+{
+    ColPtr c; c.sz = a.sz;
+    c.p = (i >= a.lo0 && i <= a.hi0 && j >= a.lo1 && j <= a.hi1) ? a.p + ((long)a.ix(i, j, a.lo2) + (long)n * a.sn - (long)a.lo2 * a.sz) : nullptr;
+    return c;
+}
+__device__ __forceinline__ ColPtr halo_ptr(const A4 &a, const HaloCell &h)
+{
+    ColPtr c; c.sz = a.sz; c.p = h.lds >= 0 ? a.p + ((long)h.g - (long)a.lo2 * a.sz) : nullptr;
+    return c;
+}
+__device__ __forceinline__ double col_ld(const ColPtr &c, int k) { return c.p ? c.p[(unsigned)k * c.sz] : 0.0; }
+__device__ __forceinline__ void col_st(const ColPtr &c, int k, double v) { c.p[(unsigned)k * c.sz] = v; }
+
 // own-point load guarded by the array box (threads of a partial block outside the array contribute nothing)
 __device__ __forceinline__ double ld_in(const A4 &a, int i, int j, int k)
 { return (i >= a.lo0 && i <= a.hi0 && j >= a.lo1 && j <= a.hi1) ? a(i, j, k) : 0.0; }
