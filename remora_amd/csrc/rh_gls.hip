@@ -123,7 +123,7 @@ __device__ __forceinline__ double pre_flux_y(const A4 &q, int n, const A4 &mskv,
     return tf * 0.5 * (q(i, j - 1, k, n) + q(i, j, k, n) - cff * (gp - gm));
 }
 // vertical flux of component n through rho-level k (k = 0..N), given cf = the transport there (:161-193 and :620-640)
-__device__ __forceinline__ double vert_flux(const A4 &q, int n, int i, int j, int k, int N, double cf)
+template <class Q> __device__ __forceinline__ double vert_flux(const Q &q, int n, int i, int j, int k, int N, double cf)
 {
     if (k == 0) { const double a = 1.0 / 3.0, b = 5.0 / 6.0, c = 1.0 / 6.0; return cf * (a * q(i, j, 0, n) + b * q(i, j, 1, n) - c * q(i, j, 2, n)); }
     if (k == N) { const double a = 1.0 / 3.0, b = 5.0 / 6.0, c = 1.0 / 6.0; return cf * (a * q(i, j, k + 1, n) + b * q(i, j, k, n) - c * q(i, j, k - 1, n)); }
@@ -457,10 +457,14 @@ k_gls_hadv_tiled(B3 b, A4 tke2, A4 gls2, A4 tkn, A4 gln, A4 Huon, A4 Hvom, A4 pm
 // back-substitution upward, the length-scale limit, stability functions and the new Akv / Akt / Akk / Akp / Lscale.
 // wA = elimination coefficients (tke, then gls), wB = the gls diagonal BCP kept between the two sweeps.
 __global__ void __launch_bounds__(RH_BX * RH_BY)
-k_gls_column(B3 bx, A4 tke, A4 gls, A4 W, A4 Akv, A4 Akt, A4 Akk, A4 Akp, A4 Lscale, A4 Hz, A4 pm, A4 pn, A4 z_w,
-             A4 sustr, A4 svstr, A4 bustr, A4 bvstr, A4 B2, A4 S2, A4 wA, A4 wB, int nstp, int nnew, double dt, GlsC g)
+k_gls_column(B3 bx, A4 tke_a, A4 gls_a, A4 W_a, A4 Akv_a, A4 Akt_a, A4 Akk_a, A4 Akp_a, A4 Lscale_a, A4 Hz_a, A4 pm, A4 pn, A4 z_w_a,
+             A4 sustr, A4 svstr, A4 bustr, A4 bvstr, A4 B2_a, A4 S2_a, A4 wA_a, A4 wB_a, int nstp, int nnew, double dt, GlsC g)
 {
     RH_IJ(bx); if (!inb2(bx, i, j)) return;
+    // column views: the (i, j) part of every 3-D access of this kernel is this thread's own column (rh_tile.h, column cursors)
+    const ColV tke = col_view(tke_a, i, j), gls = col_view(gls_a, i, j), W = col_view(W_a, i, j), Akv = col_view(Akv_a, i, j), Akt = col_view(Akt_a, i, j),
+               Akk = col_view(Akk_a, i, j), Akp = col_view(Akp_a, i, j), Lscale = col_view(Lscale_a, i, j), Hz = col_view(Hz_a, i, j), z_w = col_view(z_w_a, i, j),
+               B2 = col_view(B2_a, i, j), S2 = col_view(S2_a, i, j), wA = col_view(wA_a, i, j), wB = col_view(wB_a, i, j);
     const int N = g.N;
     const double cffA = dt * pm(i, j, 0) * pn(i, j, 0), cffd = -0.5 * dt;
     // Dirichlet values at the surface and the bottom (:732-745)
@@ -473,7 +477,7 @@ k_gls_column(B3 bx, A4 tke, A4 gls, A4 W, A4 Akv, A4 Akt, A4 Akk, A4 Akp, A4 Lsc
     { const double cff_gls = g.fac4 * g.bot_len_n; gls(i, j, 0, nnew) = dmax_(cff_gls * gpow(tke_bot, (g.gls_m), g.k_m), g.Pmin); }
 
     // ---- sweep A (k = N..1)
-    auto diffc = [&](const A4 &Ak, int k) { return (k == 0 || k == N) ? 0.0 : cffd * (Ak(i, j, k) + Ak(i, j, k + 1)) / Hz(i, j, k); };
+    auto diffc = [&](const ColV &Ak, int k) { return (k == 0 || k == N) ? 0.0 : cffd * (Ak(i, j, k) + Ak(i, j, k + 1)) / Hz(i, j, k); };
     double faK = vert_flux(tke, 2, i, j, N, N, 0.5 * (W(i, j, N + 1) + W(i, j, N)));
     double faP = vert_flux(gls, 2, i, j, N, N, 0.5 * (W(i, j, N + 1) + W(i, j, N)));
     double fdK = diffc(Akk, N), fdP = diffc(Akp, N);

@@ -91,6 +91,16 @@ __device__ __forceinline__ ColPtr halo_ptr(const A4 &a, const HaloCell &h)
 __device__ __forceinline__ double col_ld(const ColPtr &c, int k) { return c.p ? c.p[(unsigned)k * c.sz] : 0.0; }
 __device__ __forceinline__ void col_st(const ColPtr &c, int k, double v) { c.p[(unsigned)k * c.sz] = v; }
 
+// The same for kernels whose threads only ever touch their own column: a view with the call syntax of A4 whose (i, j) arguments are
+// ignored -- a(i, j, k[, n]) is level k (component n) of THE column the view was made for.  The point must lie inside the array.
+struct ColV {
+    double *p; unsigned sz, sn;
+    __device__ __forceinline__ double &operator()(int, int, int k) const { return p[(unsigned)k * sz]; }
+    __device__ __forceinline__ double &operator()(int, int, int k, int n) const { return p[(unsigned)k * sz + (unsigned)n * sn]; }
+};
+__device__ __forceinline__ ColV col_view(const A4 &a, int i, int j)
+{ ColV c; c.sz = a.sz; c.sn = a.sn; c.p = a.p + ((long)a.ix(i, j, a.lo2) - (long)a.lo2 * a.sz); return c; }
+
 // own-point load guarded by the array box (threads of a partial block outside the array contribute nothing)
 __device__ __forceinline__ double ld_in(const A4 &a, int i, int j, int k)
 { return (i >= a.lo0 && i <= a.hi0 && j >= a.lo1 && j <= a.hi1) ? a(i, j, k) : 0.0; }
