@@ -342,22 +342,35 @@ enum { R2_RZSTP, R2_RZPTS, R2_RZRHS, R2_RHOS, R2_RHOA, R2_VR, R2_VP, R2_N };    
 enum { FA_RHS, FA_STP, FA_NEW, FA_RRHS, FA_RSTP, FA_RPTS, FA_FRC, FA_R2D0, FA_R2D1, FA_AVG1, FA_AVG2, FA_DON, FA_N };   // per face direction
 struct K2Arrays { S2 r3, r2, u2, v2, spm, spn, smu, smv, smp; double *R3[R3_N], *R2[R2_N], *U[FA_N], *V[FA_N], *pm, *pn, *msku, *mskv, *mskp; };
 struct B2v { int lo0, lo1, hi0, hi1; };      // the rank's valid cell box; every box of the kernel is this one grown / made nodal
-__global__ void __launch_bounds__(RT_BX * U_BY)
-k2d_fused(B2v vb, UVPar P, ZetaPar zp, K2Arrays A, int ghost_from_mem)
+// Even so the arguments (~170 dwords) exceed the 102 scalar registers, and what the load phase fetched but the store phases need --
+// output pointers, shapes, the time-stepping weights -- was parked in vector lanes across the whole kernel.  The kernel therefore
+// takes ONE struct and the later phases read their scalars again from the kernel-argument segment (scalar loads, served by the
+// scalar cache) through a pointer the compiler cannot trace back to the argument, so nothing has to stay live from phase to phase.
+struct K2Args { B2v vb; UVPar P; ZetaPar zp; K2Arrays A; int ghost_from_mem; };
+__device__ __forceinline__ const K2Args &k2_args_again()
 {
+    typedef const K2Args __attribute__((address_space(4))) *KP;
+    KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();     // the struct is the only argument: offset 0 of the segment
+    asm volatile("" : "+s"(kp));
+    return *(const K2Args *)kp;
+}
+__global__ void __launch_bounds__(RT_BX * U_BY)
+k2d_fused(K2Args a0)
+{
+    const B2v &vb = a0.vb; const UVPar &P = a0.P; const ZetaPar &zp = a0.zp; const K2Arrays &A = a0.A; const int ghost_from_mem = a0.ghost_from_mem;
     // advance_2d.cpp's boxes: xbxD, ybxD, their union, tbxp1, tbxp3, xgbx2, ygbx2
     const B3 xb{vb.lo0, vb.lo1, 0, vb.hi0 + 1, vb.hi1, 0}, yb{vb.lo0, vb.lo1, 0, vb.hi0, vb.hi1 + 1, 0}, un{vb.lo0, vb.lo1, 0, vb.hi0 + 1, vb.hi1 + 1, 0};
     const B3 rb{vb.lo0 - 1, vb.lo1 - 1, 0, vb.hi0 + 1, vb.hi1 + 1, 0}, g3{vb.lo0 - 3, vb.lo1 - 3, 0, vb.hi0 + 3, vb.hi1 + 3, 0};
     const B3 xg{vb.lo0 - 2, vb.lo1 - 2, 0, vb.hi0 + 3, vb.hi1 + 2, 0}, yg{vb.lo0 - 2, vb.lo1 - 2, 0, vb.hi0 + 2, vb.hi1 + 3, 0};
-    const V2 ub_rhs{A.u2, A.U[FA_RHS]}, ub_stp{A.u2, A.U[FA_STP]}, ub_new{A.u2, A.U[FA_NEW]}, rubar_rhs{A.u2, A.U[FA_RRHS]}, rubar_stp{A.u2, A.U[FA_RSTP]},
+    const V2 ub_rhs{A.u2, A.U[FA_RHS]}, ub_stp{A.u2, A.U[FA_STP]}, rubar_stp{A.u2, A.U[FA_RSTP]},
              rubar_pts{A.u2, A.U[FA_RPTS]}, rufrc{A.u2, A.U[FA_FRC]}, ru2d0{A.u2, A.U[FA_R2D0]}, ru2d1{A.u2, A.U[FA_R2D1]}, DU_avg1{A.u2, A.U[FA_AVG1]},
              DU_avg2{A.u2, A.U[FA_AVG2]}, DUon_g{A.u2, A.U[FA_DON]};
-    const V2 vb_rhs{A.v2, A.V[FA_RHS]}, vb_stp{A.v2, A.V[FA_STP]}, vb_new{A.v2, A.V[FA_NEW]}, rvbar_rhs{A.v2, A.V[FA_RRHS]}, rvbar_stp{A.v2, A.V[FA_RSTP]},
+    const V2 vb_rhs{A.v2, A.V[FA_RHS]}, vb_stp{A.v2, A.V[FA_STP]}, rvbar_stp{A.v2, A.V[FA_RSTP]},
              rvbar_pts{A.v2, A.V[FA_RPTS]}, rvfrc{A.v2, A.V[FA_FRC]}, rv2d0{A.v2, A.V[FA_R2D0]}, rv2d1{A.v2, A.V[FA_R2D1]}, DV_avg1{A.v2, A.V[FA_AVG1]},
              DV_avg2{A.v2, A.V[FA_AVG2]}, DVom_g{A.v2, A.V[FA_DON]};
-    const V2 zeta_rhs{A.r3, A.R3[R3_ZRHS]}, zeta_stp{A.r3, A.R3[R3_ZSTP]}, zeta_new{A.r3, A.R3[R3_ZNEW]}, h{A.r3, A.R3[R3_H]}, fcor{A.r3, A.R3[R3_FCOR]},
+    const V2 zeta_rhs{A.r3, A.R3[R3_ZRHS]}, zeta_stp{A.r3, A.R3[R3_ZSTP]}, h{A.r3, A.R3[R3_H]}, fcor{A.r3, A.R3[R3_FCOR]},
              mskr{A.r3, A.R3[R3_MSKR]}, Zt_avg1{A.r3, A.R3[R3_ZT]};
-    const V2 rzeta_stp{A.r2, A.R2[R2_RZSTP]}, rzeta_pts{A.r2, A.R2[R2_RZPTS]}, rzeta_rhs{A.r2, A.R2[R2_RZRHS]}, rhoS{A.r2, A.R2[R2_RHOS]},
+    const V2 rzeta_stp{A.r2, A.R2[R2_RZSTP]}, rzeta_pts{A.r2, A.R2[R2_RZPTS]}, rhoS{A.r2, A.R2[R2_RHOS]},
              rhoA{A.r2, A.R2[R2_RHOA]}, visc2_r{A.r2, A.R2[R2_VR]}, visc2_p{A.r2, A.R2[R2_VP]};
     const V2 pm{A.spm, A.pm}, pn{A.spn, A.pn}, msku{A.smu, A.msku}, mskv{A.smv, A.mskv}, mskp{A.smp, A.mskp};
 
@@ -457,6 +470,13 @@ k2d_fused(B2v vb, UVPar P, ZetaPar zp, K2Arrays A, int ghost_from_mem)
     const FTile ubr{tl + T_UB * F_N, I0 - 2, J0 - 2}, vbr{tl + T_VB * F_N, I0 - 2, J0 - 2}, tpmv{tl + T_PM * F_N, I0 - 2, J0 - 2}, tpnv{tl + T_PN * F_N, I0 - 2, J0 - 2};
     // ---- (4) time averages (:293-356) and free surface (:379-464) on this thread's rho point
     double zn0 = 0.0, zw0 = 0.0, pm0 = 0.0, pn0 = 0.0;
+    double gz0 = 0, gz20 = 0, gSA0 = 0;
+    double UFx = 0, VFe = 0, mUFx = 0, mVFe = 0, corU = 0, corV = 0, UFe = 0, VFx = 0, mUFe = 0, mVFx = 0;
+    {   // phases (4), (5): parameters, output pointers and shapes read again from the argument segment (these names shadow the early ones)
+    const K2Args &L = k2_args_again();
+    const ZetaPar &zp = L.zp; const UVPar &P = L.P;
+    const V2 Zt_avg1{L.A.r3, L.A.R3[R3_ZT]}, zeta_new{L.A.r3, L.A.R3[R3_ZNEW]}, rzeta_rhs{L.A.r2, L.A.R2[R2_RZRHS]};
+    const V2 DU_avg1{L.A.u2, L.A.U[FA_AVG1]}, DU_avg2{L.A.u2, L.A.U[FA_AVG2]}, DV_avg1{L.A.v2, L.A.V[FA_AVG1]}, DV_avg2{L.A.v2, L.A.V[FA_AVG2]};
     if (in_rb) {
         pm0 = tpmv(i, j, 0); pn0 = tpnv(i, j, 0);
         const double du0 = DUon(i, j, 0), dv0 = DVom(i, j, 0);
@@ -497,10 +517,7 @@ k2d_fused(B2v vb, UVPar P, ZetaPar zp, K2Arrays A, int ghost_from_mem)
         }
     }
     // ---- (5) phase 1 of k2d_uvbar: the shared quantities of this thread's rho and psi point
-    double *q = lds + tid;
     const double fac = 1000.0 / 1025.0;
-    double gz0 = 0, gz20 = 0, gSA0 = 0;
-    double UFx = 0, VFe = 0, mUFx = 0, mVFe = 0, corU = 0, corV = 0, UFe = 0, VFx = 0, mUFe = 0, mVFx = 0;
     if (in_rb) {
         gz0 = (fac + rS0) * zw0; gz20 = gz0 * zw0; gSA0 = zw0 * (rS0 - rA0);
         UFx = s2_UFx(ubr, DUon, i, j, P);
@@ -526,13 +543,20 @@ k2d_fused(B2v vb, UVPar P, ZetaPar zp, K2Arrays A, int ghost_from_mem)
         mUFe = p.om_p * p.om_p * p.visc * cffp;
         mVFx = p.on_p * p.on_p * p.visc * cffp;
     }
+    }
+    double *q = lds + tid;
     __syncthreads();                                        // every thread is done with the tiles: the slots may overwrite them
     q[Q_UFX * NT] = UFx; q[Q_VFE * NT] = VFe; q[Q_MUFX * NT] = mUFx; q[Q_MVFE * NT] = mVFe; q[Q_CORU * NT] = corU; q[Q_CORV * NT] = corV;
     q[Q_GZ * NT] = gz0; q[Q_GZ2 * NT] = gz20; q[Q_GSA * NT] = gSA0; q[Q_H * NT] = h0; q[Q_ZW * NT] = zw0; q[Q_RA * NT] = rA0;
     q[Q_PM * NT] = pm0; q[Q_PN * NT] = pn0; q[Q_UFE * NT] = UFe; q[Q_VFX * NT] = VFx; q[Q_MUFE * NT] = mUFe; q[Q_MVFX * NT] = mVFx;
     q[Q_ZN * NT] = zn0;
     __syncthreads();
-    // ---- (6) phase 2 of k2d_uvbar
+    // ---- (6) phase 2 of k2d_uvbar (scalars read again, as above)
+    {
+    const K2Args &L = k2_args_again();
+    const UVPar &P = L.P;
+    const V2 ub_new{L.A.u2, L.A.U[FA_NEW]}, rubar_rhs{L.A.u2, L.A.U[FA_RRHS]}, rufrc{L.A.u2, L.A.U[FA_FRC]}, ru2d0{L.A.u2, L.A.U[FA_R2D0]}, ru2d1{L.A.u2, L.A.U[FA_R2D1]};
+    const V2 vb_new{L.A.v2, L.A.V[FA_NEW]}, rvbar_rhs{L.A.v2, L.A.V[FA_RRHS]}, rvfrc{L.A.v2, L.A.V[FA_FRC]}, rv2d0{L.A.v2, L.A.V[FA_R2D0]}, rv2d1{L.A.v2, L.A.V[FA_R2D1]};
     const double cffg = 0.5 * P.g, third = 1.0 / 3.0;
     if (is_u) {
         const double *w = q - 1, *n = q + RT_BX;
@@ -625,6 +649,7 @@ k2d_fused(B2v vb, UVPar P, ZetaPar zp, K2Arrays A, int ghost_from_mem)
         else vb_new(i, j, 0) = (v_stp * (Dstp0 + Dstp1) +
                                 cff * (P.c1 * rhs + P.c2 * v_rs - P.c3 * v_rp)) * Dnew_avg * mv;
         if (P.predictor) rvbar_rhs(i, j, 0) = rhs;
+    }
     }
 }
 
@@ -872,8 +897,8 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
             KA.pm = s->pm.p; KA.pn = s->pn.p; KA.msku = s->msku.p; KA.mskv = s->mskv.p; KA.mskp = s->mskp.p;
             if (s->pm.lo[2] != 0 || s->pn.lo[2] != 0 || s->msku.lo[2] != 0 || s->mskv.lo[2] != 0 || s->mskp.lo[2] != 0) return rh_fail("rh_advance_2d: 2-D arrays must sit on the k = 0 slab");
             const B2v vbx{b2.lo[0], b2.lo[1], b2.hi[0], b2.hi[1]};
-            k2d_fused<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(vbx, P, zp, KA,
-                                                                    fb_work ? 1 : 0);
+            K2Args ka; ka.vb = vbx; ka.P = P; ka.zp = zp; ka.A = KA; ka.ghost_from_mem = fb_work ? 1 : 0;
+            k2d_fused<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ka);
             RH_LAUNCH_CHECK();
         } else
         k2d_uvbar<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), mkB(tbxp1), P, mkA(ub_rhs), mkA(vb_rhs),
