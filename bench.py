@@ -50,9 +50,9 @@ GROUP_KERNELS = {
 
 
 def pmc_traffic(group, cells):
-    """HBM-side bytes per launch of the group's kernel from the committed PMC passes (profiles/r1_v6_traffic.json, collected with
+    """HBM-side bytes per launch of the group's kernel from the committed PMC passes (profiles/r1_v10_traffic.json, collected with
     tools/pmc_traffic.sh on this same workload and calibrated as MI355X_MICROARCH.md prescribes); None if absent or another size."""
-    path = os.path.join(ROOT, "profiles", "r1_v6_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_v10_traffic.json")
     if not os.path.exists(path) or group not in GROUP_KERNELS:
         return None
     with open(path) as f:

@@ -153,7 +153,7 @@ struct rh_ctx {
     // stream, runs pack -> send/recv -> unpack -> BC passes on xstream with its own message slots, and is joined before the consumer
     hipStream_t xstream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_comm = nullptr;
     double *d_xbuf2 = nullptr; long xcap2 = 0;
-    bool async_on = false, async_pending = false, in_advance = false, no_async = false;
+    bool async_on = false, async_pending = false, in_advance = false, no_async = false, async_rccl = false;
     hipStream_t last_comm_stream = nullptr; bool comm_used = false;
     // per-kernel-group timing
     bool timing = false;

@@ -256,6 +256,10 @@ static void async_swap(rh_ctx *c)
 int halo_async_begin(rh_ctx *c)
 {
     if (c->no_async || c->async_on) return 0;
+    // Built-in RCCL transport: one communicator would be driven from two streams.  The event in comm_exchange keeps its operations in
+    // issue order, but that combination has only run through the one-rank self-test so far (the decomposition tests drive the side
+    // stream through the exchange hook), so it stays opt-in (RH_ASYNC_RCCL=1) until it has run on a multi-GPU node.
+    if (c->comm && !c->async_rccl) return 0;
     RH_TRY(bc_flush(c));
     RH_TRY(halo_async_join(c));                          // one scope in flight at a time
     if (!c->xstream) {
