@@ -205,6 +205,7 @@ int  launch_uv_ab3(rh_ctx *c, rh_state *s, int istep);
 int  launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied);   // fused: AB3 + vert_visc_3d + vert_mean_3d for u, v
 int  launch_mask_cons(rh_ctx *c, rh_state *s);
 int  launch_rho_eos_P(rh_ctx *c, rh_state *s, rh_box bx, rh_box pbx);
+int  launch_prestep_uv2(rh_ctx *c, rh_state *s, rh_box bx, rh_box dead_u, rh_box dead_v, int iic, int ntfirst, int nrhs, int N, double dt);
 int  launch_prestep_uv(rh_ctx *c, rh_box vel_bx, rh_box dead, int ioff, int joff, rh_array4 vel, rh_array4 vel_old, rh_array4 rvel,
                        rh_array4 Hz, rh_array4 sstr, rh_array4 bstr, rh_array4 pm, rh_array4 pn, int iic, int ntfirst, int nrhs, int N, double dt);
 int  launch_prestep_t3(rh_ctx *c, rh_state *s, int iic, int ntfirst);   // fused: 3 tracers x (prestep_t + t3dmix)

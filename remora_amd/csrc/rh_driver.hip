@@ -115,8 +115,10 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
         const rh_box tbxp1 = bx_grow(bx, 1, 1, 0);
         // ru / rv(nrhs) on the valid faces are assigned by prsgrd below before anything reads them: prestep_uv skips that store there
         const rh_box none = bx_make(0, 0, 0, -1, -1, -1);
-        RH_TRY(launch_prestep_uv(c, tbxp1, c->unfused ? none : bx_nodal(bx, 0), 1, 0, s->xvel_new, s->xvel_old, s->ru, s->Hz, s->sustr, s->bustr, s->pm, s->pn, iic, ntfirst, nrhs, N, dt));
-        RH_TRY(launch_prestep_uv(c, tbxp1, c->unfused ? none : bx_nodal(bx, 1), 0, 1, s->yvel_new, s->yvel_old, s->rv, s->Hz, s->svstr, s->bvstr, s->pm, s->pn, iic, ntfirst, nrhs, N, dt));
+        if (c->unfused) {
+            RH_TRY(launch_prestep_uv(c, tbxp1, none, 1, 0, s->xvel_new, s->xvel_old, s->ru, s->Hz, s->sustr, s->bustr, s->pm, s->pn, iic, ntfirst, nrhs, N, dt));
+            RH_TRY(launch_prestep_uv(c, tbxp1, none, 0, 1, s->yvel_new, s->yvel_old, s->rv, s->Hz, s->svstr, s->bvstr, s->pm, s->pn, iic, ntfirst, nrhs, N, dt));
+        } else RH_TRY(launch_prestep_uv2(c, s, tbxp1, bx_nodal(bx, 0), bx_nodal(bx, 1), iic, ntfirst, nrhs, N, dt));
     }
     {
         TScope t(c, "halo");
