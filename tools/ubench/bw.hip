@@ -41,6 +41,10 @@ template <class V, int U> __global__ void t3V(double *d, const double *a, const 
     #pragma unroll
     for (int u = 0; u < U; u++) { long i = base + (long)u * blockDim.x; if (i < n2) ((V *)d)[i] = x[u] + y[u] * z[u]; }
 }
+__global__ void r1(double *d, const double *s, long n) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) { double v = s[i]; if (v == 1.2345e300) d[i] = v; } }
+__global__ void w1(double *d, long n, double v) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) d[i] = v; }
+__global__ void r2w1(double *d, const double *a, const double *b, long n) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) d[i] = a[i] + b[i]; }
+__global__ void r2w2(double *d, double *e, const double *a, const double *b, long n) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) { double x = a[i], y = b[i]; d[i] = x + y; e[i] = x - y; } }
 int main()
 {
     const long n = 2054L * 2054 * 50;           // one 3-D component of the bench grid (1.69 GB)
@@ -53,6 +57,10 @@ int main()
         printf("%-34s %8.3f ms  %6.2f TB/s\n", name, best, bytes / (best * 1e-3) / 1e12); fflush(stdout);
     };
     const int T = 256; const long n2 = n / 2;
+    run("read only 8B/lane, 1 elem/thread", 8.0 * n, [&] { r1<<<(n + T - 1) / T, T>>>(buf[0], buf[1], n); });
+    run("write only 8B/lane, 1 elem/thread", 8.0 * n, [&] { w1<<<(n + T - 1) / T, T>>>(buf[0], n, 1.0); });
+    run("2r1w 8B/lane, 1 elem/thread", 24.0 * n, [&] { r2w1<<<(n + T - 1) / T, T>>>(buf[0], buf[1], buf[2], n); });
+    run("2r2w 8B/lane, 1 elem/thread", 32.0 * n, [&] { r2w2<<<(n + T - 1) / T, T>>>(buf[0], buf[3], buf[1], buf[2], n); });
     run("copy 8B/lane, 1 elem/thread", 16.0 * n, [&] { c1<<<(n + T - 1) / T, T>>>(buf[0], buf[1], n); });
     run("copy 8B/lane, 4 elems/thread", 16.0 * n, [&] { cU<4><<<(n + T * 4 - 1) / (T * 4), T>>>(buf[0], buf[1], n); });
     run("copy 8B/lane, 8 elems/thread", 16.0 * n, [&] { cU<8><<<(n + T * 8 - 1) / (T * 8), T>>>(buf[0], buf[1], n); });
