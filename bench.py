@@ -35,6 +35,7 @@ ALGO_DOUBLES = {
     "prsgrd": 4 + 2,               # rho, P, z_r, Hz -> ru, rv
     "rho_eos": 4 + 3,              # T, S, Hz, z_r -> rho, bvf, P   (the hydrostatic pressure of prsgrd rides on the same sweep)
     "omega": 3 + 1,                # Huon, Hvom, z_w -> W
+    "massflux_omega": 4 + 3,       # uold, vold, Hz, z_w -> Huon, Hvom, W   (setup_step: old mass fluxes + omega in one sweep)
     "prestep_uv": 4 + 3,           # vel_old, Hz, rvel x2 -> vel, rvel x2
     "stretch_transform": 0 + 3,
     "vmix": 0 + 4,
@@ -44,7 +45,7 @@ ALGO_DOUBLES = {
 GROUP_KERNELS = {
     "prestep_t3": ["k_tracers_tiled<0"], "rhs_t3": ["k_tracers_tiled<1"], "rhs_uv_3d": ["k_rhs_uv_tiled"], "uv3dmix": ["k_uv3dmix_tiled"],
     "uv_corrector": ["k_column_solver_reg<1, 0, 1", "k_column_solver_reg<0, 1, 1"], "vert_visc_3d": ["k_column_solver_reg<0, 0, 0"],
-    "update_massflux_3d": ["k_massflux_lds"], "prsgrd": ["k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos_P"], "omega": ["k_omega_lds"],
+    "update_massflux_3d": ["k_massflux_lds"], "prsgrd": ["k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos_P"], "omega": ["k_omega_lds"], "massflux_omega": ["k_massflux_omega"],
     "prestep_uv": ["k_prestep_uv"], "stretch_transform": ["k_stretch"], "vmix": ["k_vmix"], "massflux_old": ["k_massflux_old"],
 }
 

@@ -199,6 +199,7 @@ struct BcScope { rh_ctx *c; BcScope(rh_ctx *ctx) : c(ctx) { bc_begin(c); } ~BcSc
 // kernels without a C entry point of their own (rh_setup.hip, rh_adv3d.hip, rh_step2d.hip)
 int  launch_bstress(rh_ctx *c, rh_state *s);
 int  launch_massflux_old(rh_ctx *c, rh_state *s);
+int  launch_massflux_omega(rh_ctx *c, rh_state *s, rh_box gbx1, int N, int *applied);
 int  launch_vmix(rh_ctx *c, rh_state *s);
 int  launch_set_zeta(rh_ctx *c, rh_state *s);
 int  launch_uv_ab3(rh_ctx *c, rh_state *s, int istep);

@@ -96,7 +96,10 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
         RH_TRY(halo_fillpatch(c, mfv(c, s->bvstr, 0, 1, 0), s->mskv, RH_BCV_V2D_SIMPLE, 0, 1));
         RH_TRY(bcs.end());
     }
-    { TScope t(c, "massflux_old"); RH_TRY(launch_massflux_old(c, s)); }                            // :187-197
+    // :187-197.  With the predictor on, the old mass fluxes are formed by the kernel that integrates omega from them (below): nothing
+    // in between reads Huon / Hvom
+    const bool defer_mf = P.use_prestep && !c->unfused;
+    if (!defer_mf) { TScope t(c, "massflux_old"); RH_TRY(launch_massflux_old(c, s)); }
     if (c->unfused) RH_TRY(rh_rho_eos(c, bx_grow(bx, 2, 2, 0), s->cons_old, c->rho, s->rhoA, s->rhoS, s->bvf, s->Hz, s->z_w, s->z_r, s->h, s->mskr, N));   // :200
     else RH_TRY(launch_rho_eos_P(c, s, bx_grow(bx, 2, 2, 0), bx_grow(bx, 1, 1, 0)));     // + the hydrostatic pressure of prsgrd (:229-260), same operands
     if (P.vmix_mode != RH_VMIX_GLS) RH_TRY(set_analytical_vmix(c, s));                             // :202-205
@@ -105,7 +108,12 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     if (P.use_prestep) RH_TRY(zero_outside(c, c->W, bx_grow(bx, 1, 1, 0))); else RH_TRY(dev_setval(c, c->W, 0, 1, 0.0));
     bool fused_t = false;
     if (P.use_prestep) {                                                                           // :216, REMORA_prestep.cpp
-        RH_TRY(rh_omega(c, bx_grow(bx, 1, 1, 0), c->W, s->Huon, s->Hvom, s->z_w, s->h, N));        // prestep_t_advection.cpp:97-125 (identical for all tracers)
+        int mo = 0;
+        if (defer_mf) RH_TRY(launch_massflux_omega(c, s, bx_grow(bx, 1, 1, 0), N, &mo));
+        if (!mo) {
+            if (defer_mf) { TScope t(c, "massflux_old"); RH_TRY(launch_massflux_old(c, s)); }
+            RH_TRY(rh_omega(c, bx_grow(bx, 1, 1, 0), c->W, s->Huon, s->Hvom, s->z_w, s->h, N));    // prestep_t_advection.cpp:97-125 (identical for all tracers)
+        }
         fused_t = !c->unfused;
         if (fused_t) RH_TRY(launch_prestep_t3(c, s, iic, ntfirst));             // 3 tracers x (prestep_t + t3dmix of :283-286) in one sweep
         else

@@ -212,6 +212,123 @@ k_omega_lds(B3 b, A4 W, A4 Huon, A4 Hvom, A4 z_w, A4 h, int N)
 #pragma unroll
     for (int u = 0; u < D; u++) { const int k = kb + u; if (k <= N) { const double x = sW[k * 64] - wrk * (zr[u] + hh); if (act) W(i, j, k) = x; } }
 }
+// setup_step's pair "mass fluxes of the old velocities" (:187-197) + omega (prestep_t_advection.cpp:97-125) in one sweep: the wave that
+// integrates a column forms Huon / Hvom of its faces from uold, vold, Hz (k_massflux_old's expressions), stores them, and feeds them
+// to the integration from registers, so the two flux arrays are not read back (k_massflux_old + k_omega_lds moved 11.4 doubles per
+// cell, this moves ~7).  It covers the faces omega touches (u faces b.lo0 .. b.hi0+1, v faces b.lo1 .. b.hi1+1 of the rows / columns
+// of b); the ghost faces outside are left to k_massflux_old on four strips per array (launch_massflux_omega).
+#define MO_D 6
+template <int D>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2)))
+k_massflux_omega(B3 b, A4 W, A4 Huon, A4 Hvom, A4 uold, A4 vold, A4 Hz, A4 pm, A4 pn, A4 z_w, A4 h, int N)
+{
+    extern __shared__ double om_lds[];
+    const int lane = threadIdx.x;
+    double *sW = om_lds + lane;                                       // sW[k * 64], k = 1 .. N+1
+    const RhTile rh_t_ = rh_tile_patch<1, 4>();
+    const int i = b.lo0 + rh_t_.x * 63 + lane, j = b.lo1 + rh_t_.y;
+    const bool act = lane < 63 && i <= b.hi0;
+    const int ic = i <= b.hi0 ? i : b.hi0;
+    const int iu = i <= b.hi0 + 1 ? i : b.hi0 + 1;
+    const bool st_u = i <= b.hi0 + 1 && (lane < 63 || i == b.hi0 + 1);     // this lane owns the u face iu (lane 63's is the next wave's lane 0)
+    const bool st_v1 = act && j == b.hi1;                             // the top row also owns its upper v faces
+    const double on_u = 2.0 / (pn(iu - 1, j, 0) + pn(iu, j, 0));
+    const double om_v0 = 2.0 / (pm(ic, j - 1, 0) + pm(ic, j, 0)), om_v1 = 2.0 / (pm(ic, j, 0) + pm(ic, j + 1, 0));
+    struct L { double u, hu0, hu1, v0, v1, hm, hp; };
+    auto load = [&](int kk) -> L {                                    // level kk (clamped) of the operands
+        const int kc = kk < N ? kk : N;
+        L r; r.u = uold(iu, j, kc); r.hu0 = Hz(iu, j, kc); r.hu1 = Hz(iu - 1, j, kc);
+        r.v0 = vold(ic, j, kc); r.v1 = vold(ic, j + 1, kc); r.hm = Hz(ic, j - 1, kc); r.hp = Hz(ic, j + 1, kc);
+        return r;
+    };
+    double w = 0.0;
+    auto step = [&](int k, const L &c) {                              // fluxes of level k-1, then W(k) = W(k-1) - dHuon(k-1) - dHvom(k-1)
+        const double hu = 0.5 * (c.hu0 + c.hu1) * c.u * on_u;
+        const double hv0 = 0.5 * (c.hu0 + c.hm) * c.v0 * om_v0;       // for the lanes that use it (i <= b.hi0) iu == ic: hu0 is Hz(ic, j)
+        const double hv1 = 0.5 * (c.hp + c.hu0) * c.v1 * om_v1;
+        if (st_u) Huon(iu, j, k - 1) = hu;
+        if (act) Hvom(ic, j, k - 1) = hv0;
+        if (st_v1) Hvom(ic, j + 1, k - 1) = hv1;
+        const double up = __shfl_down(hu, 1);
+        w = w - (up - hu) - (hv1 - hv0);
+        sW[k * 64] = w;
+    };
+    L ring[D];
+#pragma unroll
+    for (int u = 0; u < D; u++) ring[u] = load(u);
+    int kb = 1;
+    for (; kb + D - 1 <= N + 1; kb += D) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            step(kb + u, ring[u]);
+            __builtin_amdgcn_sched_barrier(0);
+            ring[u] = load(kb + u - 1 + D);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < D; u++) if (kb + u <= N + 1) step(kb + u, ring[u]);
+    // ---- remove the part proportional to (z_w + h), :111-125
+    const double hh = h(ic, j, 0, 0);
+    const double wrk = w / (z_w(ic, j, N + 1) + hh);
+    if (act) { W(i, j, 0) = 0.0; W(i, j, N + 1) = 0.0; }
+    double zr[D];
+#pragma unroll
+    for (int u = 0; u < D; u++) { const int k = 1 + u; zr[u] = z_w(ic, j, k < N ? k : N); }
+    kb = 1;
+    for (; kb + D - 1 <= N; kb += D) {
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            const int k = kb + u;
+            const double x = sW[k * 64] - wrk * (zr[u] + hh);
+            if (act) W(i, j, k) = x;
+            __builtin_amdgcn_sched_barrier(0);
+            const int kn = k + D; zr[u] = z_w(ic, j, kn < N ? kn : N);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < D; u++) { const int k = kb + u; if (k <= N) { const double x = sW[k * 64] - wrk * (zr[u] + hh); if (act) W(i, j, k) = x; } }
+}
+// *applied = 0: the caller runs launch_massflux_old and rh_omega
+int launch_massflux_omega(rh_ctx *c, rh_state *s, rh_box gbx1, int N, int *applied)
+{
+    *applied = 0;
+    rh_box b = gbx1; b.lo[2] = 0; b.hi[2] = N; rh_box bw = b; bw.hi[2] = N + 1;
+    const size_t lds_bytes = sizeof(double) * (size_t)(N + 2) * 64;
+    if (c->unfused || lds_bytes > RH_LDS_MAX) return 0;
+    const rh_box bu = bx_of(s->Huon), bv = bx_of(s->Hvom);
+    rh_box cu = bx_nodal(b, 0), cv = bx_nodal(b, 1);                  // the faces the fused kernel writes
+    if (bx_and(bu, cu).lo[0] != cu.lo[0] || bx_and(bu, cu).hi[0] != cu.hi[0] || bx_and(bu, cu).lo[1] != cu.lo[1] || bx_and(bu, cu).hi[1] != cu.hi[1] ||
+        bx_and(bv, cv).lo[0] != cv.lo[0] || bx_and(bv, cv).hi[0] != cv.hi[0] || bx_and(bv, cv).lo[1] != cv.lo[1] || bx_and(bv, cv).hi[1] != cv.hi[1] ||
+        bu.lo[2] != 0 || bu.hi[2] != N || bv.lo[2] != 0 || bv.hi[2] != N) return 0;
+    TScope t(c, "massflux_omega");
+    RH_NEED(c->W, bw); RH_NEED(s->z_w, bw); RH_NEED(s->h, bx_slab(b, 2, 0));
+    RH_NEED(s->Hz, bx_growlo_i(bu)); RH_NEED(s->Hz, bx_growlo_j(bv)); RH_NEED(s->xvel_old, bu); RH_NEED(s->yvel_old, bv);
+    RH_NEED(s->pn, bx_slab(bx_growlo_i(bu), 2, 0)); RH_NEED(s->pm, bx_slab(bx_growlo_j(bv), 2, 0));
+    RH_NEED(s->Hz, bx_grow(b, 1, 1, 0)); RH_NEED(s->pm, bx_slab(bx_grow(b, 1, 1, 0), 2, 0)); RH_NEED(s->pn, bx_slab(bx_grow(b, 1, 1, 0), 2, 0));
+    // ghost faces outside the fused kernel's reach: four strips per flux array
+    const rh_box none = bx_make(0, 0, 0, -1, -1, -1);
+    auto strips = [&](const rh_box &arr, const rh_box &cov, bool is_u) -> int {
+        rh_box q[4] = {arr, arr, arr, arr};
+        q[0].hi[1] = cov.lo[1] - 1;                                                   // rows below
+        q[1].lo[1] = cov.hi[1] + 1;                                                   // rows above
+        q[2].lo[1] = cov.lo[1]; q[2].hi[1] = cov.hi[1]; q[2].hi[0] = cov.lo[0] - 1;   // columns left
+        q[3].lo[1] = cov.lo[1]; q[3].hi[1] = cov.hi[1]; q[3].lo[0] = cov.hi[0] + 1;   // columns right
+        for (const rh_box &r : q) {
+            if (r.lo[0] > r.hi[0] || r.lo[1] > r.hi[1]) continue;
+            k_massflux_old<<<grid3(r), rh_block(), 0, c->stream>>>(mkB(is_u ? r : none), mkB(is_u ? none : r), mkB(r), mkA(s->Hz), mkA(s->Huon), mkA(s->Hvom),
+                                                                   mkA(s->xvel_old), mkA(s->yvel_old), mkA(s->pm), mkA(s->pn));
+            RH_LAUNCH_CHECK();
+        }
+        return 0;
+    };
+    RH_TRY(strips(bu, cu, true)); RH_TRY(strips(bv, cv, false));
+    RH_HIP(rh_lds_optin(k_massflux_omega<MO_D>, lds_bytes));
+    const dim3 grid((b.hi[0] - b.lo[0] + 63) / 63, b.hi[1] - b.lo[1] + 1, 1);         // waves overlap by one column
+    k_massflux_omega<MO_D><<<grid, 64, lds_bytes, c->stream>>>(mkB(b), mkA(c->W), mkA(s->Huon), mkA(s->Hvom), mkA(s->xvel_old), mkA(s->yvel_old), mkA(s->Hz),
+                                                              mkA(s->pm), mkA(s->pn), mkA(s->z_w), mkA(s->h), N);
+    RH_LAUNCH_CHECK();
+    *applied = 1; return 0;
+}
 extern "C" int rh_omega(rh_ctx *c, rh_box gbx1, rh_array4 W, rh_array4 Huon, rh_array4 Hvom, rh_array4 z_w, rh_array4 h, int N)
 {
     TScope t(c, "omega");
