@@ -45,10 +45,13 @@ __global__ void r1(double *d, const double *s, long n) { long i = (long)blockIdx
 __global__ void w1(double *d, long n, double v) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) d[i] = v; }
 __global__ void r2w1(double *d, const double *a, const double *b, long n) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) d[i] = a[i] + b[i]; }
 __global__ void r2w2(double *d, double *e, const double *a, const double *b, long n) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) { double x = a[i], y = b[i]; d[i] = x + y; e[i] = x - y; } }
-int main()
+__global__ void fill_rand(double *d, long n, unsigned long long seed) { long i = (long)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) { unsigned long long x = (unsigned long long)i * 6364136223846793005ULL + seed; x ^= x >> 29; x *= 0xbf58476d1ce4e5b9ULL; x ^= x >> 32; d[i] = 1.0 + (double)(x >> 11) * (1.0 / 9007199254740992.0); } }
+int main(int argc, char **argv)
 {
     const long n = 2054L * 2054 * 50;           // one 3-D component of the bench grid (1.69 GB)
     double *buf[4]; for (auto &p : buf) { CK(hipMalloc((void **)&p, (n + 2) * 8)); CK(hipMemset(p, 0, (n + 2) * 8)); }
+    if (argc > 1) { for (int q = 0; q < 4; q++) fill_rand<<<(n + 255) / 256, 256>>>(buf[q], n, 12345ULL + q); hipDeviceSynchronize(); printf("buffers hold random doubles in [1, 2)\n"); }
+    else printf("buffers hold zeros\n");
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto run = [&](const char *name, double bytes, auto launch) {
         launch(); hipDeviceSynchronize();
