@@ -6,13 +6,21 @@ of the DoubleGyre physics (Exec/DoubleGyre, Tests/test_files/DoubleGyre/DoubleGy
 (BASELINE.json configs[3]).  With N > 1 the domain is 2048 x (2048 N) x 50, split into N j-slabs
 (weak scaling; --grid PXxPY picks another i-j process grid), and every FillBoundary becomes RCCL send/recv with the neighbours.
 
+Launch: `python bench.py --gpus N` from a bare shell starts its own N ranks (fresh child processes, started before this
+process touches a GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one rank of N.
+
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline     -- the dominant kernel group of the step, measured live with HIP events on the library's stream
-  cpu_baseline -- the CPU oracle (oracle/, a single-threaded restatement of the reference's path) timed on a bounded sample
+  roofline     -- the dominant kernel of the step (largest share of the step's time), measured live with HIP events on the
+                  library's stream: algorithmic bytes per launch / mean launch duration against the 8 TB/s HBM peak
+  kernels      -- the same figure for every kernel group of the step
+  step_roofline-- (i) union bytes of the fused 3-D kernels / time of the 3-D part, (ii) that plus the 2-D bytes / whole step
+  cpu_baseline -- the CPU oracle (oracle/, C restatement of the reference's path) timed on a bounded sample
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,9 +29,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec
 
-# Algorithmic doubles per cell per launch of each kernel group (distinct 3-D field components read + distinct
-# 3-D field components written, each counted once; 2-D arrays, scratch, halo and cache re-reads are NOT counted).  A fused group
-# counts the union of its members.
+# Algorithmic doubles per cell per launch of each 3-D kernel group (distinct 3-D field components read +
+# distinct 3-D field components written, each counted once; 2-D arrays, scratch, halo and cache re-reads are NOT counted).  A
+# fused group counts the union of its members.
 ALGO_DOUBLES = {
     "prestep_t3": 10 + 6,          # told x3, tnew x3, Hz, Huon, Hvom, W -> sstore x3, tnew x3   (3 tracers in one launch)
     "rhs_t3": 10 + 3,              # sstore x3, t x3, Huon, Hvom, Hz, W -> t x3
@@ -32,45 +40,59 @@ ALGO_DOUBLES = {
     "uv_corrector": 4 + 1,         # u, ru, Hz, Akv -> u     (AB3 + vert_visc_3d + vert_mean_3d; one launch per velocity)
     "vert_visc_3d": 3 + 1,         # phi, Hz, Akt -> phi
     "update_massflux_3d": 3 + 1,   # phi, Hphi, Hz -> Hphi (+ phi on boundary faces only)
+    "massflux_omega_new": 6 + 3,   # u, v, Huon, Hvom, Hz, z_w -> Huon, Hvom, W   (advance_3d: update_massflux_3d x2 + omega in one sweep)
     "prsgrd": 4 + 2,               # rho, P, z_r, Hz -> ru, rv
     "rho_eos": 4 + 3,              # T, S, Hz, z_r -> rho, bvf, P   (the hydrostatic pressure of prsgrd rides on the same sweep)
     "omega": 3 + 1,                # Huon, Hvom, z_w -> W
     "massflux_omega": 4 + 3,       # uold, vold, Hz, z_w -> Huon, Hvom, W   (setup_step: old mass fluxes + omega in one sweep)
-    "prestep_uv": 4 + 3,           # vel_old, Hz, rvel x2 -> vel, rvel x2
+    "prestep_uv": 7 + 4,           # k_prestep_uv2, u and v in one launch: uold, vold, Hz, ru x2, rv x2 -> u, v, ru, rv
     "stretch_transform": 0 + 3,
     "vmix": 0 + 4,
     "massflux_old": 3 + 2,
 }
-# kernel(s) behind each group in the rocprofv3 output (profiles/*_traffic.json keys start with these)
+# Algorithmic doubles per COLUMN per launch of the fused barotropic kernel k2d_fused (distinct 2-D arrays, counted in
+# remora_amd/csrc/rh_step2d.hip for the bench configuration: masks all one, Coriolis on).
+#   every call reads   zeta(krhs), zeta(kstp), h, pm, pn, ubar(krhs), vbar(krhs), ubar(kstp), vbar(kstp), rhoS, rhoA, visc2_r,
+#                      visc2_p, fcor, rufrc, rvfrc                                                                  = 16
+#   predictor adds     Zt_avg1, DU_avg1, DU_avg2, DV_avg1, DV_avg2 (read + written: 5 + 5), rzeta / rubar / rvbar(krhs)
+#                      written (3), zeta / ubar / vbar(knew) written (3)                                            -> 16 + 5 + 11 = 32
+#   corrector adds     rzeta / rubar / rvbar(kstp) and (ptsk) read (6), DU_avg2, DV_avg2 (2 + 2), the three new levels (3)
+#                                                                                                                   -> 16 + 8 + 5 = 29
+# nfast predictor and nfast corrector calls run fused per step: 30.5 on average (PMC: 32 doubles per column moved).
+K2D_DOUBLES = 30.5
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_current.json")
+# kernel(s) behind each group in the rocprofv3 output (the traffic file's keys start with these)
 GROUP_KERNELS = {
     "prestep_t3": ["k_tracers_tiled<0"], "rhs_t3": ["k_tracers_tiled<1"], "rhs_uv_3d": ["k_rhs_uv_tiled"], "uv3dmix": ["k_uv3dmix_tiled"],
     "uv_corrector": ["k_column_solver_reg<1, 0, 1", "k_column_solver_reg<0, 1, 1"], "vert_visc_3d": ["k_column_solver_reg<0, 0, 0"],
-    "update_massflux_3d": ["k_massflux_lds"], "prsgrd": ["k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos_P"], "omega": ["k_omega_lds"], "massflux_omega": ["k_massflux_omega"],
-    "prestep_uv": ["k_prestep_uv"], "stretch_transform": ["k_stretch"], "vmix": ["k_vmix"], "massflux_old": ["k_massflux_old"],
+    "update_massflux_3d": ["k_massflux_lds"], "massflux_omega_new": ["k_massflux_omega_new"], "prsgrd": ["k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos_P"],
+    "omega": ["k_omega_lds"], "massflux_omega": ["k_massflux_omega<"], "prestep_uv": ["k_prestep_uv2"], "stretch_transform": ["k_stretch"],
+    "vmix": ["k_vmix"], "massflux_old": ["k_massflux_old"], "k2d_fused": ["k2d_fused"],
 }
 
 
-def pmc_traffic(group, cells):
-    """HBM-side bytes per launch of the group's kernel from the committed PMC passes (profiles/r1_v10_traffic.json, collected with
-    tools/pmc_traffic.sh on this same workload and calibrated as MI355X_MICROARCH.md prescribes); None if absent or another size."""
-    path = os.path.join(ROOT, "profiles", "r1_v10_traffic.json")
-    if not os.path.exists(path) or group not in GROUP_KERNELS:
-        return None
-    with open(path) as f:
+def pmc_traffic(group, cells, build):
+    """Fabric-side bytes per launch of the group's kernel from the committed PMC passes (tools/pmc_traffic.sh, collected and
+    calibrated as MI355X_MICROARCH.md prescribes).  Only a file that records the SAME library build and the same grid counts:
+    returns (bytes, source) or (None, reason)."""
+    if not os.path.exists(TRAFFIC_FILE) or group not in GROUP_KERNELS:
+        return None, "no PMC traffic file for this build"
+    with open(TRAFFIC_FILE) as f:
         t = json.load(f)
+    if t.get("build") != build:
+        return None, f"profiles/traffic_current.json is of build {t.get('build')}, the library is {build}"
     if t.get("cells") != cells:
-        return None
-    tot = 0.0; n = 0
+        return None, "profiles/traffic_current.json is of another grid size"
+    tot = 0.0
     for pre in GROUP_KERNELS[group]:
         ks = [v for k, v in t["kernels"].items() if k.startswith(pre)]
         if not ks:
-            return None
-        # several instantiations of one kernel (u / v): average them; several kernels in a group (prsgrd): add them
+            return None, f"kernel {pre} not in profiles/traffic_current.json"
+        # several instantiations of one kernel (u / v): average them; several kernels in a group: add them
         tot += sum(v["read_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks) / len(ks)
-        n += 1
     if group == "uv_corrector":
         tot /= 2.0                  # its two entries are the two instantiations of one per-velocity launch
-    return tot
+    return tot, f"profiles/traffic_current.json (build {build})"
 
 
 def parse():
@@ -85,7 +107,7 @@ def parse():
                     "Upwelling (configs[4]-shaped blocks, e.g. --case Upwelling --nx 4096 --ny 2048 --nz 64)")
     ap.add_argument("--grid", type=str, default="", help="process grid PXxPY (PX * PY = --gpus); default 1xN = j-slabs, every rank keeps full 512-B-coalesced i rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=str, default="256x256x50x3", help="nx x ny x nz x steps of the CPU-oracle sample")
+    ap.add_argument("--cpu-sample", type=str, default="512x512x50x4", help="nx x ny x nz x steps of the CPU-oracle sample")
     return ap.parse_args()
 
 
@@ -108,34 +130,69 @@ def bench_case(nx_per_gpu, ny_per_gpu, nz, px, py=None, name="DoubleGyre"):
 
 
 def cpu_baseline(sample):
-    """Time the CPU oracle on a small DoubleGyre grid (same physics, same step) on the host cores of this box: the leaf passes
+    """Time the CPU oracle on a smaller DoubleGyre grid (same physics, same step) on the host cores of this box: the leaf passes
     (oracle/leaves.c) run OpenMP-threaded over j, ghost fills and glue serially, as in the reference, whose TimeIntegration loops
-    carry no OpenMP either.  The threaded run is bitwise the serial one (tests/test_oracle_gold.py)."""
-    from oracle.oracle_py import Oracle
+    carry no OpenMP either.  Timing build of the oracle (oracle/Makefile: liboracle_fast.so, -O3
+    -march=x86-64-v3), not the -O2 -ffp-contract=off parity build."""
+    from oracle import oracle_py
+    oracle_py.use_fast_build()
     nx, ny, nz, steps = (int(x) for x in sample.split("x"))
     threads = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)))   # the box's CPU share is 16
     c = bench_case(nx, ny, nz, 1)
-    o = Oracle(c, threads=threads)
+    o = oracle_py.Oracle(c, threads=threads)
     o.advance(1)                      # first step (iic = 0 branches) not timed
     t0 = time.perf_counter()
     o.advance(steps)
     dt = time.perf_counter() - t0
     o.close()
     return {"value": nx * ny * nz * steps / dt, "unit": "cell-updates/s", "cores": threads, "kind": "port",
-            "sample": f"DoubleGyre physics {nx}x{ny}x{nz}, {steps} steps after 1 untimed ({dt:.1f} s), oracle/ (C restatement, -O2, "
-                      f"OpenMP over the leaf passes, {threads} threads)"}
+            "sample": f"DoubleGyre physics {nx}x{ny}x{nz} = {nx * ny * nz} cells, {steps} steps after 1 untimed ({dt:.1f} s of CPU work), oracle/ "
+                      f"(C restatement of the reference's passes, gcc -O3 -march=x86-64-v3, OpenMP over the leaf passes, {threads} threads)"}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` from a bare shell: start N fresh rank processes (this parent never touches a GPU and never
+    imports torch), relay rank 0's JSON line, exit with the first non-zero code."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=120 if rc == 0 else 5)
+        except subprocess.TimeoutExpired:
+            p.kill()                 # the exact child we started
+            p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    sys.exit(rc)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(a.gpus)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE = {world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # REMORA_BENCH_TRANSPORT=host: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share cuda:0, messages are
@@ -143,6 +200,8 @@ def main():
     host_transport = os.environ.get("REMORA_BENCH_TRANSPORT", "") == "host"
     if host_transport:
         local = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs (found {torch.cuda.device_count()}); REMORA_BENCH_TRANSPORT=host rehearses on fewer")
     torch.cuda.set_device(local)
     if world > 1:
         if host_transport:
@@ -199,29 +258,59 @@ def main():
     rem.timing(False)
 
     cells_per_gpu = a.nx * a.ny * nz
+    cols_per_gpu = a.nx * a.ny
+    build = rem.build_id()
+    step_ms = el / a.steps * 1e3
+
+    def algo_bytes(g):
+        if g == "k2d_fused":
+            return K2D_DOUBLES * 8 * cols_per_gpu
+        return ALGO_DOUBLES[g] * 8 * cells_per_gpu
+
+    kern = {}
+    for g, v in rep.items():
+        if (g in ALGO_DOUBLES or g == "k2d_fused") and v["calls"] > 0:
+            avg_ms = v["ms"] / v["calls"]
+            ach = algo_bytes(g) / (avg_ms * 1e-3) / 1e9
+            kern[g] = {"launches_per_step": v["calls"] / nprof, "avg_launch_ms": round(avg_ms, 4), "ms_per_step": round(v["ms"] / nprof, 4),
+                       "algorithmic_GBs": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
     roof = None
-    leaf = {k: v for k, v in rep.items() if k in ALGO_DOUBLES}
-    if leaf:
-        dom = max(leaf, key=lambda k: leaf[k]["ms"])
-        avg_ms = leaf[dom]["ms"] / leaf[dom]["calls"]
-        bytes_launch = ALGO_DOUBLES[dom] * 8 * cells_per_gpu
-        ach = bytes_launch / (avg_ms * 1e-3) / 1e9
-        roof = {"kernel": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom, cells_per_gpu), "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_launch,
-                "share_of_step": leaf[dom]["ms"] / nprof / (el / a.steps * 1e3)}
+    if kern:
+        dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
+        avg_ms = rep[dom]["ms"] / rep[dom]["calls"]
+        ach = algo_bytes(dom) / (avg_ms * 1e-3) / 1e9
+        traffic, tsrc = pmc_traffic(dom, cells_per_gpu, build)
+        roof = {"kernel": GROUP_KERNELS.get(dom, [dom])[0], "group": dom, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc, "avg_launch_ms": avg_ms,
+                "algorithmic_bytes_per_launch": algo_bytes(dom), "launches_per_step": rep[dom]["calls"] / nprof,
+                "share_of_step": rep[dom]["ms"] / nprof / step_ms}
+    # step-level figures.  (i) 3-D part: union bytes of the fused 3-D kernels (each group's algorithmic bytes x its launches) over
+    # the time of setup_step + advance_3d_ml (ghost fills, small 2-D kernels and launch gaps included).  (ii) whole step: those bytes
+    # plus the barotropic kernels' bytes over the whole measured step.
+    b3 = sum(ALGO_DOUBLES[g] * 8 * cells_per_gpu * rep[g]["calls"] / nprof for g in rep if g in ALGO_DOUBLES)
+    b2 = K2D_DOUBLES * 8 * cols_per_gpu * rep["k2d_fused"]["calls"] / nprof if "k2d_fused" in rep else 0.0
+    t3 = (rep.get("setup_step", {"ms": 0})["ms"] + rep.get("advance_3d_ml", {"ms": 0})["ms"]) / nprof
+    t_all = sum(rep.get(k, {"ms": 0})["ms"] for k in ("setup_step", "advance_2d", "advance_3d_ml")) / nprof
+    step_roof = {"bytes_3d_union": b3, "doubles_per_cell_3d_union": b3 / 8 / cells_per_gpu, "ms_3d": round(t3, 3),
+                 "frac_3d": (b3 / (t3 * 1e-3) / 1e9 / HBM_PEAK_GBS) if t3 > 0 else None,
+                 "bytes_2d": b2, "ms_step_profiled": round(t_all, 3),
+                 "frac_step": ((b3 + b2) / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_all > 0 else None,
+                 "frac_3d_reference_granular": (1232.0 * cells_per_gpu / (t3 * 1e-3) / 1e9 / HBM_PEAK_GBS) if t3 > 0 else None,
+                 "note": "frac_3d = union bytes of the fused 3-D kernels / (setup_step + advance_3d_ml time); frac_step adds the k2d_fused bytes "
+                         "and divides by the whole step; frac_3d_reference_granular prices the same time against the 1232 B/cell the "
+                         "reference's own pass structure moves (SURVEY.md 8d)"}
     if rank == 0:
         out = {"metric": "3D baroclinic cell-updates/s", "value": cells_per_gpu * world * a.steps / el, "unit": "cell-updates/s",
-               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": el / a.steps * 1e3, "higher_is_better": True,
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{a.case} physics, {a.nx}x{a.ny}x{nz} cells per GPU (domain {nx}x{ny}x{nz}), "
                                       f"dt {case['fixed_dt']:.3f} s, ndtfast {case['ndtfast']}, nfast {rem.nfast}, "
                                       f"{f'{px}x{py} i-j decomposition, ghost exchange over RCCL' if world > 1 else 'single box'}",
                           "parallelism": f"ij-decomp {px}x{py}"},
-               "finite": finite, **({"transport": "host-staged gloo rehearsal (NOT the RCCL configuration)"} if host_transport else {}),
-               "roofline": roof,
-               "kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])},
-               "algorithmic_hbm_frac_step": (1232.0 * cells_per_gpu / (el / a.steps)) / 1e9 / HBM_PEAK_GBS}
-        if not a.no_cpu_baseline:
+               "finite": finite, "build": build, **({"transport": "host-staged gloo rehearsal (NOT the RCCL configuration)"} if host_transport else {}),
+               "roofline": roof, "step_roofline": step_roof, "kernels": kern,
+               "kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}}
+        if not a.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)
         if not finite:
             out["value"] = 0.0

@@ -84,6 +84,9 @@ typedef struct rh_state {
 typedef struct rh_ctx rh_ctx;
 
 const char *rh_last_error(void);
+/* Build tag of the library (bumped whenever a kernel changes): profiles/traffic_current.json records the tag of the build its PMC
+ * passes ran on, and bench.py reports those bytes only for the same build.  No counterpart in the reference. */
+const char *rh_build_id(void);
 
 /* ---- context ------------------------------------------------------------------------------------- */
 /* Builds the context: BC table (REMORA::init_bcs, Initialization/REMORA_init_bcs.cpp:9-679, SlipWall/periodic subset),
@@ -258,8 +261,9 @@ typedef struct rh_plot_box {
     long   cell_offset, nd_offset;       /* byte offsets of the two FAB records in those files */
     double cell_min[6], cell_max[6], nd_min[3], nd_max[3];
 } rh_plot_box;
-/* This rank's part: gathers the variables on the device, appends one FAB record to each of the two data files under
- * <dir>/Level_0 (created if needed) and fills *out.  Synchronises. */
+/* This rank's part: gathers the variables on the device, writes one FAB record to each of its two data files under
+ * <dir>/Level_0 (created if needed; the files are truncated first, every rank owns the files of its file_index) and fills *out.
+ * Synchronises. */
 int  rh_plotfile_write_data(rh_ctx *ctx, rh_state *s, const char *dir, int with_scalar, int file_index, rh_plot_box *out);
 /* Header, Level_0/Cell_H and Level_0/Nu_nd_H for the boxes of all ranks (host only; needs no device).  A decomposed run gathers
  * the rh_plot_box records with its own communicator and calls this on one rank. */
@@ -270,8 +274,8 @@ int  rh_write_plotfile(rh_ctx *ctx, rh_state *s, const char *dir, int with_scala
 
 /* Checkpoint / restart in the reference's layout (REMORA::WriteCheckpointFile / ReadCheckpointFile, Source/IO/REMORA_Checkpoint.cpp:
  * 15-245, 248-470): text Header + one VisMF (<Name>_H, <Name>_D_00000) per array under <dir>/Level_0, every array with its ghost
- * cells as the reference writes them (Cell, Cell_old, XFace, ..., XRHS, XBar, DU_avg1, zeta, Zt_avg1, h, Akv, Akt and, with the GLS
- * closure, tke, gls, Lscale, Akk, Akp).  rh_read_checkpoint expects a state that already holds what InitData builds without a
+ * cells as the reference writes them (Cell, Cell_old, XFace, ..., XRHS, XBar, DU_avg1, zeta, Zt_avg1, h, tke, gls, Lscale, Akk, Akp, Akv,
+ * Akt: the reference's full list, :120-202; a state without the GLS closure writes the five closure arrays as init leaves them).  rh_read_checkpoint expects a state that already holds what InitData builds without a
  * checkpoint (rh_init_state or the host's init), overwrites the checkpointed arrays and rebuilds z_w / z_r / Hz; a run continued
  * from it is bit-identical to the uninterrupted one.  One box per call; both synchronise. */
 int  rh_write_checkpoint(rh_ctx *ctx, rh_state *s, const char *dir, int step, double time);

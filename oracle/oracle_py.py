@@ -39,6 +39,18 @@ def build(force=False):
 
 
 _lib = None
+_FAST = os.path.join(_HERE, "liboracle_fast.so")
+
+
+def use_fast_build():
+    """bench.py's cpu_baseline leg only: load the -O3 timing build (oracle/Makefile: liboracle_fast.so) instead of the parity
+    build.  Must be called before the first lib() call of the process; raises if that build is missing."""
+    global _LIB
+    if _lib is not None:
+        raise RuntimeError("oracle library already loaded")
+    if not os.path.exists(_FAST):
+        raise FileNotFoundError(_FAST + " is missing: make -C oracle liboracle_fast.so")
+    _LIB = _FAST
 
 
 def lib():

@@ -151,6 +151,7 @@ struct rh_ctx {
     double *d_xbuf = nullptr; long xcap = 0;                   // 4 message slots: send_lo, send_hi, recv_lo, recv_hi (xcap doubles each)
     // side stream for ghost fills whose consumer is far away (rh_halo.hip: halo_async_*): the fill scope forks off the compute
     // stream, runs pack -> send/recv -> unpack -> BC passes on xstream with its own message slots, and is joined before the consumer
+    hipStream_t own_xstream = nullptr;                         // the side stream this context created (never swapped; rh_destroy frees this one only)
     hipStream_t xstream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_comm = nullptr;
     double *d_xbuf2 = nullptr; long xcap2 = 0;
     bool async_on = false, async_pending = false, in_advance = false, no_async = false, async_rccl = false;
@@ -195,6 +196,8 @@ int  halo_async_join(rh_ctx *c);
 void bc_begin(rh_ctx *c);
 int  bc_end(rh_ctx *c);
 int  bc_flush(rh_ctx *c);
+// side-stream scope of halo_async_begin / halo_async_end: the destructor swaps the context back on every exit path
+struct AsyncScope { rh_ctx *c; AsyncScope(rh_ctx *ctx) : c(ctx) {} ~AsyncScope() { if (c) (void)halo_async_end(c); } int begin() { return halo_async_begin(c); } int end() { rh_ctx *x = c; c = nullptr; return halo_async_end(x); } };
 struct BcScope { rh_ctx *c; BcScope(rh_ctx *ctx) : c(ctx) { bc_begin(c); } ~BcScope() { if (c) (void)bc_end(c); } int end() { rh_ctx *x = c; c = nullptr; return bc_end(x); } };
 // kernels without a C entry point of their own (rh_setup.hip, rh_adv3d.hip, rh_step2d.hip)
 int  launch_bstress(rh_ctx *c, rh_state *s);

@@ -13,6 +13,8 @@ int rh_fail(const char *fmt, ...)
     return 1;
 }
 extern "C" const char *rh_last_error(void) { return g_rh_err.c_str(); }
+#define RH_BUILD_ID "r2_v1"
+extern "C" const char *rh_build_id(void) { return RH_BUILD_ID; }
 
 // ------------------------------------------------------------------------------------------------ timing
 TScope::TScope(rh_ctx *ctx, const char *name) : c(ctx), on(ctx->timing)
@@ -277,7 +279,15 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     c->prm = *prm; c->stream = (hipStream_t)stream;
     for (int d = 0; d < 3; d++) { c->dom.lo[d] = prm->domain_lo[d]; c->dom.hi[d] = prm->domain_hi[d]; c->bx.lo[d] = prm->box_lo[d]; c->bx.hi[d] = prm->box_hi[d]; }
     c->nz = c->dom.hi[2] - c->dom.lo[2] + 1; c->N = c->nz - 1;
-    auto bad = [&](const char *m) { delete c; return rh_fail("rh_create: %s", m); };
+    // every failure leaves through here: device memory allocated so far is freed before the context
+    auto bad = [&](const char *m) {
+        const std::string msg = m;                          // m may point into g_rh_err
+        if (c->d_sc) (void)hipFree(c->d_sc);
+        if (c->d_work) (void)hipFree(c->d_work);
+        delete c;
+        return rh_fail("rh_create: %s", msg.c_str());
+    };
+    auto bad_hip = [&](const char *what, hipError_t e) { const std::string m = std::string(what) + " failed: " + hipGetErrorString(e); return bad(m.c_str()); };
     if (c->dom.lo[2] != 0) return bad("domain must start at k = 0");
     if (c->nz < 3) return bad("at least 3 vertical levels are required (4th-order vertical fluxes index k = N-2)");
     if (c->bx.lo[2] != c->dom.lo[2] || c->bx.hi[2] != c->dom.hi[2]) return bad("boxes must span the full vertical (main.cpp:21-23)");
@@ -311,9 +321,9 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     for (int k = 0; k <= nz; k++)
         stretch_coeffs(k, nz, prm->theta_s, prm->theta_b, &c->h_sc[0 * (nz + 1) + k], &c->h_sc[1 * (nz + 1) + k], &c->h_sc[2 * (nz + 1) + k], &c->h_sc[3 * (nz + 1) + k]);
     hipError_t e = hipMalloc((void **)&c->d_sc, sizeof(double) * c->h_sc.size());
-    if (e != hipSuccess) { delete c; return rh_fail("rh_create: hipMalloc failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { c->d_sc = nullptr; return bad_hip("hipMalloc", e); }
     e = hipMemcpy(c->d_sc, c->h_sc.data(), sizeof(double) * c->h_sc.size(), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { delete c; return rh_fail("rh_create: hipMemcpy failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) return bad_hip("hipMemcpy", e);
 
     // work space: rho (setup_step.cpp:63), P (prsgrd.cpp:39), W (setup_step.cpp:210, advance_3d.cpp:230),
     // CF/DC of the tridiagonal solve (advance_3d.cpp:49-51, vert_visc_3d.cpp), DUon/DVom (advance_2d.cpp:105-106)
@@ -335,17 +345,17 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
         c->gB2 = shape_of(c, 0, 0, 0, 1, 0, 0, 0); c->gS2 = c->gB2;
         for (rh_array4 *a : {&c->gW1, &c->gW2, &c->gW3, &c->gS2C, &c->gB2, &c->gS2}) ws.push_back(a);
         const rh_gls_params &G = prm->gls;
-        if (G.stability < RH_GLS_CANUTO_A || G.stability > RH_GLS_GALPERIN) { (void)hipFree(c->d_sc); return bad("unknown gls stability type"); }
+        if (G.stability < RH_GLS_CANUTO_A || G.stability > RH_GLS_GALPERIN) return bad("unknown gls stability type");
         if (G.gls_n == 0.0 || !(G.gls_cmu0 > 0.0) || !(G.gls_sigk > 0.0) || !(G.gls_sigp > 0.0) || !(G.gls_Kmin > 0.0) || !(G.gls_Pmin > 0.0))
-            { (void)hipFree(c->d_sc); return bad("gls parameters: gls_n must be non-zero; cmu0, sigk, sigp, Kmin, Pmin positive"); }
+            return bad("gls parameters: gls_n must be non-zero; cmu0, sigk, sigp, Kmin, Pmin positive");
     }
     long n = 0; for (rh_array4 *a : ws) n += align32(a4_size(*a));
     c->work_bytes = n * 8;
     e = hipMalloc((void **)&c->d_work, c->work_bytes);
-    if (e != hipSuccess) { (void)hipFree(c->d_sc); delete c; return rh_fail("rh_create: hipMalloc(%ld bytes of work space) failed: %s", n * 8, hipGetErrorString(e)); }
+    if (e != hipSuccess) { c->d_work = nullptr; char m[96]; snprintf(m, sizeof m, "hipMalloc(%ld bytes of work space)", n * 8); return bad_hip(m, e); }
     double *p = c->d_work; for (rh_array4 *a : ws) { a->p = p; p += align32(a4_size(*a)); }
     e = hipMemsetAsync(c->d_work, 0, c->work_bytes, c->stream);
-    if (e != hipSuccess) { (void)hipFree(c->d_sc); (void)hipFree(c->d_work); delete c; return rh_fail("rh_create: hipMemsetAsync failed: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) return bad_hip("hipMemsetAsync", e);
     *out = c;
     return 0;
 }
@@ -353,8 +363,10 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
 extern "C" int rh_destroy(rh_ctx *c)
 {
     if (!c) return 0;
+    if (c->async_on) (void)halo_async_end(c);                // a failed call left the side-stream scope open: swap back first
     (void)hipStreamSynchronize(c->stream);
-    if (c->xstream) { (void)hipStreamSynchronize(c->xstream); (void)hipStreamDestroy(c->xstream); }
+    // only the stream this context created is destroyed, whatever c->stream / c->xstream point at
+    if (c->own_xstream) { (void)hipStreamSynchronize(c->own_xstream); (void)hipStreamDestroy(c->own_xstream); }
     for (hipEvent_t e : {c->ev_fork, c->ev_join, c->ev_comm}) if (e) (void)hipEventDestroy(e);
     if (c->d_xbuf2) (void)hipFree(c->d_xbuf2);
     for (auto &v : c->tev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }

@@ -151,7 +151,8 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     // The ghost cells filled here are first read in advance_3d, a whole barotropic loop later: inside rh_advance the fills go to
     // the side stream (pack, send/recv, unpack and BC passes overlap the 2-D kernels) and rh_advance_3d_ml joins them.
     const bool side = c->in_advance && !c->no_async;
-    if (side) RH_TRY(halo_async_begin(c));
+    AsyncScope as(side ? c : nullptr);                      // swaps back (and records the join event) on every exit path
+    if (side) RH_TRY(as.begin());
     {
         TScope t(c, "halo");
         BcScope bcs(c);
@@ -160,7 +161,7 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
         RH_TRY(halo_fill_boundary(c, mfv(c, s->Hvom, 0, 1, 0), 0, 1));
         RH_TRY(bcs.end());
     }
-    if (side) RH_TRY(halo_async_end(c));
+    if (side) RH_TRY(as.end());
     return 0;
 }
 

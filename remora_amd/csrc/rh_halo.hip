@@ -264,6 +264,7 @@ int halo_async_begin(rh_ctx *c)
     RH_TRY(halo_async_join(c));                          // one scope in flight at a time
     if (!c->xstream) {
         RH_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+        c->own_xstream = c->xstream;
         RH_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); RH_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     }
     RH_HIP(hipEventRecord(c->ev_fork, c->stream));

@@ -9,6 +9,7 @@
 // diagnostics synchronise.  Every rank writes its own data file; the headers take the list of all boxes (rank 0, after a gather).
 #include "rh_common.h"
 #include <sstream>
+#include <algorithm>
 #include <sys/stat.h>
 #include <cerrno>
 
@@ -37,10 +38,11 @@ static std::string box_str(const rh_box &b, int nodal)
     snprintf(s, sizeof s, "((%d,%d,%d) (%d,%d,%d) (%d,%d,%d))", b.lo[0], b.lo[1], b.lo[2], b.hi[0], b.hi[1], b.hi[2], nodal, nodal, nodal);
     return s;
 }
-// one FAB record appended to `path`; returns the offset it starts at
+// one FAB record written to `path` (truncated first: every rank owns its data file and writes exactly one record per plotfile, so
+// a repeated write into an existing directory must not grow the file); returns the offset the record starts at
 static int write_fab(const std::string &path, const rh_box &b, int nodal, int ncomp, const double *data, long *offset)
 {
-    FILE *f = fopen(path.c_str(), "ab");
+    FILE *f = fopen(path.c_str(), "wb");
     if (!f) return rh_fail("plotfile: cannot open %s: %s", path.c_str(), strerror(errno));
     fseek(f, 0, SEEK_END);
     *offset = ftell(f);
@@ -161,8 +163,6 @@ extern "C" int rh_write_plotfile(rh_ctx *c, rh_state *s, const char *dir, int wi
 {
     if (c->prm.nranks[0] * c->prm.nranks[1] > 1)
         return rh_fail("rh_write_plotfile: decomposed runs gather their rh_plot_box records and call rh_plotfile_write_headers on one rank");
-    // start from empty data files: the writer appends
-    if (dir) { const std::string d1 = std::string(dir) + "/Level_0"; (void)remove((d1 + "/Cell_D_00000").c_str()); (void)remove((d1 + "/Nu_nd_D_00000").c_str()); }
     rh_plot_box b;
     RH_TRY(rh_plotfile_write_data(c, s, dir, with_scalar, 0, &b));
     return rh_plotfile_write_headers(&c->prm, dir, with_scalar, step, time, 1, &b);
@@ -192,6 +192,14 @@ static const ChkField g_chk[] = {
     {"Akk", &rh_state::Akk, 0, 0, 1, 1}, {"Akp", &rh_state::Akp, 0, 0, 1, 1},
     {"Akv", &rh_state::Akv, 0, 0, 1, 0}, {"Akt", &rh_state::Akt, 0, 0, 1, 0},
 };
+// shape of the reference's GLS arrays on this rank's box: w-points, ghost widths (NGROW, NGROW, 0) (make_new_level.cpp:499-503)
+static rh_array4 gls_shape(const rh_ctx *c, int ncomp)
+{
+    rh_array4 a; a.p = nullptr; a.ncomp = ncomp;
+    const rh_box b = bx_grow(bx_nodal(c->bx, 2), RH_NGROW, RH_NGROW, 0);
+    for (int d = 0; d < 3; d++) { a.lo[d] = b.lo[d]; a.hi[d] = b.hi[d]; }
+    return a;
+}
 static std::string box_str_ix(const rh_box &b, int ix0, int ix1, int ix2)
 {
     char s[160];
@@ -206,14 +214,29 @@ extern "C" int rh_write_checkpoint(rh_ctx *c, rh_state *s, const char *dir, int 
     RH_TRY(make_dir(d0)); RH_TRY(make_dir(d1));
     RH_HIP(hipStreamSynchronize(c->stream));
     std::vector<double> h;
+    const bool have_gls = c->prm.vmix_mode == RH_VMIX_GLS;
     for (const ChkField &f : g_chk) {
-        const rh_array4 &a = s->*(f.m);
-        if (f.gls_only && c->prm.vmix_mode != RH_VMIX_GLS) continue;
-        if (!a.p) return rh_fail("rh_write_checkpoint: state array %s is not bound", f.name);
+        rh_array4 a = s->*(f.m);
+        // The reference writes tke / gls / Lscale / Akk / Akp whatever the mixing scheme (:196-200) and reads them back
+        // unconditionally (:448-452).  A state without the closure has no such arrays: they are written in the reference's shape
+        // (w-points, ghost widths (2,2,0), 3/3/1/1/1 components, make_new_level.cpp:499-503) holding what init leaves there
+        // (gls_Kmin, gls_Pmin, 0, Akk_bak, Akp_bak: make_new_level.cpp:517-521; defaults of REMORA_DataStruct.H:430-443).
+        const bool synth = f.gls_only && !have_gls;
+        double fill = 0.0;
+        if (synth) {
+            const rh_gls_params &G = c->prm.gls;
+            const bool tk = !strcmp(f.name, "tke"), gl = !strcmp(f.name, "gls");
+            a = gls_shape(c, (tk || gl) ? 3 : 1);
+            if (tk) fill = G.gls_Kmin > 0.0 ? G.gls_Kmin : 7.6e-6;
+            else if (gl) fill = G.gls_Pmin > 0.0 ? G.gls_Pmin : 1.0e-12;
+            else if (!strcmp(f.name, "Akk")) fill = G.Akk_bak > 0.0 ? G.Akk_bak : 5.0e-6;
+            else if (!strcmp(f.name, "Akp")) fill = G.Akp_bak > 0.0 ? G.Akp_bak : 5.0e-6;
+        } else if (!a.p) return rh_fail("rh_write_checkpoint: state array %s is not bound", f.name);
         const MFV m = mfv(c, a, f.ix0, f.ix1, f.ix2);
         const long n = a4_size(a), n3 = n / a.ncomp;
         h.resize((size_t)n);
-        RH_HIP(hipMemcpy(h.data(), a.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
+        if (synth) std::fill(h.begin(), h.end(), fill);
+        else RH_HIP(hipMemcpy(h.data(), a.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
         const std::string base = d1 + "/" + f.name;
         FILE *fd = fopen((base + "_D_00000").c_str(), "wb");
         if (!fd) return rh_fail("rh_write_checkpoint: cannot open %s_D_00000: %s", base.c_str(), strerror(errno));
@@ -272,6 +295,7 @@ extern "C" int rh_read_checkpoint(rh_ctx *c, rh_state *s, const char *dir, int *
     std::vector<double> h;
     for (const ChkField &f : g_chk) {
         const rh_array4 &a = s->*(f.m);
+        // a state without the closure has nowhere to put tke / gls / Lscale / Akk / Akp (nothing on its path reads them)
         if (f.gls_only && c->prm.vmix_mode != RH_VMIX_GLS) continue;
         if (!a.p) return rh_fail("rh_read_checkpoint: state array %s is not bound", f.name);
         const std::string base = d1 + "/" + f.name;

@@ -898,7 +898,7 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
             if (s->pm.lo[2] != 0 || s->pn.lo[2] != 0 || s->msku.lo[2] != 0 || s->mskv.lo[2] != 0 || s->mskp.lo[2] != 0) return rh_fail("rh_advance_2d: 2-D arrays must sit on the k = 0 slab");
             const B2v vbx{b2.lo[0], b2.lo[1], b2.hi[0], b2.hi[1]};
             K2Args ka; ka.vb = vbx; ka.P = P; ka.zp = zp; ka.A = KA; ka.ghost_from_mem = fb_work ? 1 : 0;
-            k2d_fused<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ka);
+            { TScope tk(c, "k2d_fused"); k2d_fused<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ka); }
             RH_LAUNCH_CHECK();
         } else
         k2d_uvbar<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), mkB(tbxp1), P, mkA(ub_rhs), mkA(vb_rhs),

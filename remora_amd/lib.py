@@ -104,6 +104,7 @@ _A = Array4
 _SP = C.POINTER(State)
 SIGNATURES = {
     "rh_last_error": (C.c_char_p, []),
+    "rh_build_id": (C.c_char_p, []),
     "rh_create": (C.c_int, [C.POINTER(Params), _P, C.POINTER(_P)]),
     "rh_destroy": (C.c_int, [_P]),
     "rh_nfast": (C.c_int, [_P]),

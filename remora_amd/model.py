@@ -282,6 +282,9 @@ class REMORA:
         L.check(self.lib.rh_sum_integrated_quantities(self.ctx, C.byref(self.state), int(local_only), out))
         return tuple(out)
 
+    def build_id(self):
+        return self.lib.rh_build_id().decode()
+
     # ---- per-kernel timing ---------------------------------------------------------------------------------
     def timing(self, on=True):
         L.check(self.lib.rh_timing_enable(self.ctx, int(on)))

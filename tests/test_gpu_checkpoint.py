@@ -52,3 +52,57 @@ def test_checkpoint_of_another_decomposition_is_refused(tmp_path):
     with pytest.raises(L.RemoraHipError, match="same decomposition"):
         c.ReadCheckpointFile(tmp_path / "chk")
     c.close()
+
+
+# the VisMFs REMORA::WriteCheckpointFile writes for every run, GLS or not (IO/REMORA_Checkpoint.cpp:120-202), with the
+# (components, ghost widths) the reference allocates them with (Initialization/REMORA_make_new_level.cpp:259-282,426-503)
+REFERENCE_LIST = {"Cell": (3, "3"), "Cell_old": (3, "3"), "XFace": (1, "3"), "XFace_old": (1, "3"), "YFace": (1, "3"), "YFace_old": (1, "3"),
+                  "ZFace": (1, "(3,3,0)"), "ZFace_old": (1, "(3,3,0)"), "XRHS": (2, "(2,2,0)"), "YRHS": (2, "(2,2,0)"),
+                  "XBar": (3, "(2,2,0)"), "YBar": (3, "(2,2,0)"), "XRHS2d": (2, "(2,2,0)"), "YRHS2d": (2, "(2,2,0)"),
+                  "Mskr": (1, "(3,3,0)"), "Msku": (1, "(3,3,0)"), "Mskv": (1, "(3,3,0)"), "rdrag": (1, "(2,2,0)"),
+                  "DU_avg1": (1, "(2,2,0)"), "DU_avg2": (1, "(2,2,0)"), "DV_avg1": (1, "(2,2,0)"), "DV_avg2": (1, "(2,2,0)"),
+                  "zeta": (3, "(3,3,0)"), "Zt_avg1": (1, "(3,3,0)"), "h": (2, "(3,3,0)"),
+                  "tke": (3, "(2,2,0)"), "gls": (3, "(2,2,0)"), "Lscale": (1, "(2,2,0)"), "Akk": (1, "(2,2,0)"), "Akp": (1, "(2,2,0)"),
+                  "Akv": (1, "(2,2,0)"), "Akt": (3, "(2,2,0)")}
+
+
+@pytest.mark.parametrize("case", ["Seamount", "Upwelling_GLS"])
+def test_checkpoint_holds_the_reference_file_list(case, tmp_path):
+    """A checkpoint of a run WITHOUT the GLS closure must still hold tke / gls / Lscale / Akk / Akp: the reference reads them
+    unconditionally (REMORA_Checkpoint.cpp:448-452).  Parity unpinned (the reference ships no checkpoint fixture): the list and
+    shapes are checked against the reference's source."""
+    cfg = cases.get(case)
+    b = REMORA(cfg); b.InitData(); b.Evolve(1)
+    chk = tmp_path / "chk00001"
+    b.WriteCheckpointFile(chk)
+    nx, ny, nz = cfg["ncell"]
+    lev = os.path.join(chk, "Level_0")
+    names = sorted(f[:-2] for f in os.listdir(lev) if f.endswith("_H"))
+    assert names == sorted(REFERENCE_LIST), set(names) ^ set(REFERENCE_LIST)
+    for name, (ncomp, ng) in REFERENCE_LIST.items():
+        hdr = open(os.path.join(lev, name + "_H")).read().split("\n")
+        assert hdr[0] == "1" and hdr[1] == "1" and int(hdr[2]) == ncomp, (name, hdr[:4])
+        assert hdr[3] == ng, (name, hdr[3])
+        assert os.path.getsize(os.path.join(lev, name + "_D_00000")) > 0
+    if "gls" not in cfg:
+        # what init leaves in a run without the closure: gls_Kmin, gls_Pmin, 0, Akk_bak, Akp_bak (make_new_level.cpp:517-521)
+        for name, val, ncomp in (("tke", 7.6e-6, 3), ("gls", 1.0e-12, 3), ("Lscale", 0.0, 1), ("Akk", 5.0e-6, 1), ("Akp", 5.0e-6, 1)):
+            raw = open(os.path.join(lev, name + "_D_00000"), "rb").read()
+            head, body = raw.split(b"\n", 1)
+            assert head.endswith(b"(0,0,1)) %d" % ncomp), head
+            a = np.frombuffer(body, dtype="<f8")
+            assert a.size == ncomp * (nx + 4) * (ny + 4) * (nz + 1) and np.all(a == val), name
+    b.close()
+
+
+def test_plotfile_rewrite_does_not_grow(tmp_path):
+    """A second plotfile written into the same directory replaces the data files (one FAB record per rank and file)."""
+    cfg = cases.get("Seamount")
+    b = REMORA(cfg); b.InitData()
+    d = tmp_path / "plt"
+    b.WritePlotFile(d)
+    n1 = os.path.getsize(os.path.join(d, "Level_0", "Cell_D_00000"))
+    pb = b.write_plot_data(d, 0)
+    assert pb.cell_offset == 0 and pb.nd_offset == 0
+    assert os.path.getsize(os.path.join(d, "Level_0", "Cell_D_00000")) == n1
+    b.close()
