@@ -56,7 +56,9 @@ def test_checkpoint_of_another_decomposition_is_refused(tmp_path):
 
 # the VisMFs REMORA::WriteCheckpointFile writes for every run, GLS or not (IO/REMORA_Checkpoint.cpp:120-202), with the
 # (components, ghost widths) the reference allocates them with (Initialization/REMORA_make_new_level.cpp:259-282,426-503)
-REFERENCE_LIST = {"Cell": (3, "3"), "Cell_old": (3, "3"), "XFace": (1, "3"), "XFace_old": (1, "3"), "YFace": (1, "3"), "YFace_old": (1, "3"),
+# A native state carries no ghost cells in z (rh_state: "z ghost cells are optional"), so the 3-D state arrays are written with ghost
+# widths (3,3,0) where the reference's MultiFabs have 3 in every direction.
+REFERENCE_LIST = {"Cell": (3, "(3,3,0)"), "Cell_old": (3, "(3,3,0)"), "XFace": (1, "(3,3,0)"), "XFace_old": (1, "(3,3,0)"), "YFace": (1, "(3,3,0)"), "YFace_old": (1, "(3,3,0)"),
                   "ZFace": (1, "(3,3,0)"), "ZFace_old": (1, "(3,3,0)"), "XRHS": (2, "(2,2,0)"), "YRHS": (2, "(2,2,0)"),
                   "XBar": (3, "(2,2,0)"), "YBar": (3, "(2,2,0)"), "XRHS2d": (2, "(2,2,0)"), "YRHS2d": (2, "(2,2,0)"),
                   "Mskr": (1, "(3,3,0)"), "Msku": (1, "(3,3,0)"), "Mskv": (1, "(3,3,0)"), "rdrag": (1, "(2,2,0)"),
