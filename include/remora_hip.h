@@ -238,6 +238,13 @@ int  rh_est_timestep(rh_ctx *ctx, rh_state *s, double cfl, int local_only, doubl
 /* REMORA::sum_integrated_quantities + volWgtSumMF, Source/REMORA_SumIQ.cpp:9-141: out4 = { sum scalar*vol, sum kineng*vol, sum vol,
  * max speed } with vol = Hz / (pm pn) and the ROMS kinetic energy of :38-40.  Sums across ranks as above.  Synchronises. */
 int  rh_sum_integrated_quantities(rh_ctx *ctx, rh_state *s, int local_only, double out4[4]);
+/* The same reduction for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Rank-local (as local_only = 1 above), the four values are written to
+ * out4_device (DEVICE memory of the caller, 4 doubles) by kernels enqueued on the context's stream; the call allocates nothing,
+ * copies nothing to the host and does not synchronise.  The per-block partials live in a static device array of 41,000 bytes per
+ * GPU (fixed launch geometry, so one size serves every box; boxes of 2^32 cells or more are refused with an error).  All calls
+ * on one GPU share that array: calls that overlap on one GPU race -- issue them on one stream or order them yourself. */
+int  rh_sum_integrated_quantities_noalloc(rh_ctx *ctx, rh_state *s, double *out4_device);
 
 /* ---- synthetic initial state (outside the hot path; what InitData / prob.cpp provide in REMORA) ---- */
 /* Fills a bound native state for one of the pinned problems (0 Upwelling, 1 Seamount, 2 DoubleGyre, 3 Advection, 4 DoublyPeriodic, 5 Channel_Test):

@@ -148,6 +148,7 @@ struct rh_ctx {
     void *comm = nullptr; int rank = 0, nranks = 1;
     rh_exchange_fn xfn = nullptr; void *xuser = nullptr;      // transport of the ghost exchange (RCCL by default)
     double *d_diag = nullptr;                                  // per-block partials of the diagnostics reductions (rh_diag.hip)
+    int device = -1; double *d_scratch = nullptr;              // this context's GPU and the address of rh_diag.hip's static scratch array on it
     double *d_xbuf = nullptr; long xcap = 0;                   // 4 message slots: send_lo, send_hi, recv_lo, recv_hi (xcap doubles each)
     // side stream for ghost fills whose consumer is far away (rh_halo.hip: halo_async_*): the fill scope forks off the compute
     // stream, runs pack -> send/recv -> unpack -> BC passes on xstream with its own message slots, and is joined before the consumer
@@ -220,4 +221,5 @@ int  comm_exchange(rh_ctx *c, long n_lo, int peer_lo, long n_hi, int peer_hi);  
 int  dev_setval(rh_ctx *c, const rh_array4 &a, int icomp, int ncomp, double v);
 int  dev_copy(rh_ctx *c, const rh_array4 &dst, const rh_array4 &src);
 int  dev_setbox(rh_ctx *c, const rh_array4 &a, int comp, rh_box b, double v);      // rh_driver.hip
+int  diag_scratch_init(rh_ctx *c);                                                 // rh_diag.hip
 int  launch_gls_init(rh_ctx *c, rh_state *s);                                      // rh_gls.hip

@@ -356,6 +356,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     double *p = c->d_work; for (rh_array4 *a : ws) { a->p = p; p += align32(a4_size(*a)); }
     e = hipMemsetAsync(c->d_work, 0, c->work_bytes, c->stream);
     if (e != hipSuccess) return bad_hip("hipMemsetAsync", e);
+    if (diag_scratch_init(c)) { const std::string m = g_rh_err; return bad(m.c_str()); }
     *out = c;
     return 0;
 }

@@ -68,23 +68,30 @@ __global__ void __launch_bounds__(64) k_diag_final(const double *__restrict__ pa
     if (threadIdx.x == 0) { out[DG_CFL] = cfl; out[DG_KEMAX] = kemax; out[DG_SCALAR] = ssum; out[DG_KINENG] = ksum; out[DG_VOLUME] = vsum; }
 }
 
-// rank-local reduction of this rank's valid box; host copy of the 5 values (synchronises the context's stream)
-static int diag_local(rh_ctx *c, rh_state *s, double h[DG_N])
+// the two launches of the rank-local reduction of this rank's valid box: per-block partials into `part` (DG_BLOCKS x DG_N doubles,
+// every one of them rewritten by every call), the 5 folded values into `out`
+static int diag_launch(rh_ctx *c, rh_state *s, double *part, double *out)
 {
     const rh_box bx = c->bx;
     RH_NEED(s->cons_new, bx); RH_NEED(s->xvel_new, bx_nodal(bx, 0)); RH_NEED(s->yvel_new, bx_nodal(bx, 1)); RH_NEED(s->zvel_new, bx_nodal(bx, 2));
     RH_NEED(s->Hz, bx); RH_NEED(s->pm, bx_slab(bx, 2, 0)); RH_NEED(s->pn, bx_slab(bx, 2, 0));
     if (s->cons_new.ncomp < RH_NCONS) return rh_fail("diagnostics: cons_new needs %d components", RH_NCONS);
-    if (!c->d_diag) RH_HIP(hipMalloc((void **)&c->d_diag, sizeof(double) * (DG_BLOCKS + 2) * DG_N));
     const rh_params &P = c->prm;
     double dxi[3];
     for (int d = 0; d < 3; d++) dxi[d] = (double)(c->dom.hi[d] - c->dom.lo[d] + 1) / (P.prob_hi[d] - P.prob_lo[d]);   // geom.InvCellSizeArray()
-    double *part = c->d_diag, *out = c->d_diag + (long)DG_BLOCKS * DG_N;
     k_diag_partial<<<DG_BLOCKS, DG_THREADS, 0, c->stream>>>(mkB(bx), mkA(s->cons_new), mkA(s->xvel_new), mkA(s->yvel_new), mkA(s->zvel_new),
         mkA(s->Hz), mkA(s->pm), mkA(s->pn), dxi[0], dxi[1], dxi[2], 2 /* Scalar_comp, REMORA_IndexDefines.H:8-11 */, part);
     RH_LAUNCH_CHECK();
     k_diag_final<<<1, 64, 0, c->stream>>>(part, out);
     RH_LAUNCH_CHECK();
+    return 0;
+}
+// rank-local reduction; host copy of the 5 values (synchronises the context's stream)
+static int diag_local(rh_ctx *c, rh_state *s, double h[DG_N])
+{
+    if (!c->d_diag) RH_HIP(hipMalloc((void **)&c->d_diag, sizeof(double) * (DG_BLOCKS + 2) * DG_N));
+    double *part = c->d_diag, *out = c->d_diag + (long)DG_BLOCKS * DG_N;
+    RH_TRY(diag_launch(c, s, part, out));
     RH_HIP(hipMemcpyAsync(h, out, sizeof(double) * DG_N, hipMemcpyDeviceToHost, c->stream));
     RH_HIP(hipStreamSynchronize(c->stream));
     return 0;
@@ -128,5 +135,63 @@ extern "C" int rh_sum_integrated_quantities(rh_ctx *c, rh_state *s, int local_on
     RH_TRY(diag_allreduce(c, h, local_only));
     out4[0] = h[DG_SCALAR]; out4[1] = h[DG_KINENG]; out4[2] = h[DG_VOLUME];
     out4[3] = sqrt(2.0 * h[DG_KEMAX]);                                                        // SumIQ.cpp:45
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The entry point that allocates nothing (include/remora_hip.h: rh_sum_integrated_quantities_noalloc; no counterpart in the
+// reference).  Same kernels as above; the per-block partials live in a file-scope device array instead of the context's hipMalloc'd
+// buffer, and the four results go to a device address of the caller's, so the call issues two kernel launches plus one tiny one and
+// nothing else: no hipMalloc / hipFree, no host copy, no synchronisation.
+//   scratch: (DG_BLOCKS + 1) x DG_N doubles = 41,000 bytes per GPU, held until the process ends.  The launch geometry is fixed, so
+//   the array serves every box size the kernels index (the limit is the 2^32-element bound of RH_NEED, stated in the error).
+//   Every GPU holds its own copy at its own address: the address is looked up once per device, with that device current
+//   (diag_scratch_init, called by rh_create), and only that pointer -- never the array's name -- is handed to kernels.
+//   All calls on one GPU share the array: every call rewrites all of it before reading it (nothing has to start at zero), and two
+//   calls that overlap on one GPU (different streams or contexts) race.
+#define DG_SCRATCH_DOUBLES ((DG_BLOCKS + 1) * DG_N)
+#define DG_NOALLOC_MAX_CELLS (1L << 32)
+static __device__ __align__(256) double scratch[DG_SCRATCH_DOUBLES];
+#define DG_MAX_DEVICES 64
+static double *g_scratch_ptr[DG_MAX_DEVICES];            // per device: the address of `scratch` on that GPU (0 = not looked up yet)
+#include <mutex>
+static std::mutex g_scratch_mu;
+
+int diag_scratch_init(rh_ctx *c)
+{
+    int dev = -1;
+    RH_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= DG_MAX_DEVICES) return rh_fail("diagnostics: device ordinal %d outside [0, %d)", dev, DG_MAX_DEVICES);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        double *p = nullptr;
+        RH_HIP(hipGetSymbolAddress((void **)&p, HIP_SYMBOL(scratch)));
+        if (!p) return rh_fail("diagnostics: hipGetSymbolAddress returned a null address for the scratch array");
+        g_scratch_ptr[dev] = p;
+    }
+    c->device = dev; c->d_scratch = g_scratch_ptr[dev];
+    return 0;
+}
+
+// out4 = { sum scalar*vol, sum kineng*vol, sum vol, max speed } on the device (SumIQ.cpp:45 for the last one)
+__global__ void k_diag_out4(const double *__restrict__ folded, double *__restrict__ out4)
+{
+    if (threadIdx.x == 0) { out4[0] = folded[DG_SCALAR]; out4[1] = folded[DG_KINENG]; out4[2] = folded[DG_VOLUME]; out4[3] = sqrt(2.0 * folded[DG_KEMAX]); }
+}
+
+extern "C" int rh_sum_integrated_quantities_noalloc(rh_ctx *c, rh_state *s, double *out4_device)
+{
+    if (!c || !s || !out4_device) return rh_fail("rh_sum_integrated_quantities_noalloc: null argument");
+    if (!c->d_scratch) return rh_fail("rh_sum_integrated_quantities_noalloc: the context has no scratch address (rh_create looks it up)");
+    int dev = -1;
+    RH_HIP(hipGetDevice(&dev));
+    if (dev != c->device) return rh_fail("rh_sum_integrated_quantities_noalloc: device %d is current, the context lives on device %d", dev, c->device);
+    const long cells = bx_npts(c->bx);
+    if (cells >= DG_NOALLOC_MAX_CELLS)
+        return rh_fail("rh_sum_integrated_quantities_noalloc: box of %ld cells; this entry point serves boxes below %ld cells (32-bit indexing)", cells, DG_NOALLOC_MAX_CELLS);
+    double *part = c->d_scratch, *folded = c->d_scratch + (long)DG_BLOCKS * DG_N;
+    RH_TRY(diag_launch(c, s, part, folded));
+    k_diag_out4<<<1, 64, 0, c->stream>>>(folded, out4_device);
+    RH_LAUNCH_CHECK();
     return 0;
 }

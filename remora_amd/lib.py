@@ -119,6 +119,7 @@ SIGNATURES = {
     "rh_halo_plan_j": (C.c_int, [C.POINTER(Params), C.c_int * 3, C.c_int * 3, C.c_int * 3, C.POINTER(HaloPlan)]),
     "rh_est_timestep": (C.c_int, [C.c_void_p, C.POINTER(State), C.c_double, C.c_int, C.POINTER(C.c_double)]),
     "rh_sum_integrated_quantities": (C.c_int, [C.c_void_p, C.POINTER(State), C.c_int, C.c_double * 4]),
+    "rh_sum_integrated_quantities_noalloc": (C.c_int, [C.c_void_p, C.POINTER(State), C.c_void_p]),
     "rh_halo_plan_i": (C.c_int, [C.POINTER(Params), C.c_int * 3, C.c_int * 3, C.c_int * 3, C.POINTER(HaloPlan)]),
     "rh_fill_boundary": (C.c_int, [_P, _A, C.c_int * 3, C.c_int, C.c_int]),
     "rh_physbc": (C.c_int, [_P, _A, C.c_int * 3, _A, C.c_int, C.c_int, C.c_int]),
