@@ -69,8 +69,25 @@ static inline void fab_setval(Fab f,double v){ long n=fab_size(f); for(long q=0;
 static inline Fab fab_comp(Fab f,int n){ f.p+=f.sn*(long)n; f.nc-=n; return f; }
 
 #define IX(f,i,j,k)     ((long)((i)-(f).lo[0]) + (long)((j)-(f).lo[1])*(f).sy + (long)((k)-(f).lo[2])*(f).sz)
+#ifdef ORACLE_BOUNDS
+/* checking build (oracle/Makefile: liboracle_chk.so): every access is tested against the Fab's box and component count, so a test
+ * harness that hands a leaf an array too small for its stencil aborts with the place instead of reading past the end */
+#include <stdio.h>
+static inline double *fab_at(Fab f,int i,int j,int k,int n,const char *file,int line)
+{
+    if(i<f.lo[0]||i>f.hi[0]||j<f.lo[1]||j>f.hi[1]||k<f.lo[2]||k>f.hi[2]||n<0||n>=f.nc){
+        fprintf(stderr,"oracle: access (%d,%d,%d,%d) outside Fab (%d:%d,%d:%d,%d:%d) x %d at %s:%d\n",i,j,k,n,
+                f.lo[0],f.hi[0],f.lo[1],f.hi[1],f.lo[2],f.hi[2],f.nc,file,line);
+        abort();
+    }
+    return f.p+IX(f,i,j,k)+(long)n*f.sn;
+}
+#define V(f,i,j,k)      (*fab_at((f),(i),(j),(k),0,__FILE__,__LINE__))
+#define VN(f,i,j,k,n)   (*fab_at((f),(i),(j),(k),(n),__FILE__,__LINE__))
+#else
 #define V(f,i,j,k)      ((f).p[IX(f,i,j,k)])
 #define VN(f,i,j,k,n)   ((f).p[IX(f,i,j,k) + (long)(n)*(f).sn])
+#endif
 
 /* loop over a box in the order amrex::ParallelFor uses on the CPU (k outer, i inner).  Every such loop restates one
  * amrex::ParallelFor pass, whose iterations are independent by contract (the same lambdas run as GPU kernels), so the j

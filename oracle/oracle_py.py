@@ -170,3 +170,87 @@ def set_weights(ndtfast):
     w2 = np.zeros(2 * ndtfast + 1)
     nfast = lib().o_set_weights(ndtfast, w1.ctypes.data, w2.ctypes.data)
     return nfast, w1, w2
+
+
+# ---- leaf level: the Box / Fab / Geom structs of oracle/fab.h and oracle/oracle.h, so that tests can call the leaf restatements
+# (o_rhs_t_3d, o_rhs_uv_3d, ...) directly on seeded arrays.  Structs are passed by value, as the C functions take them.
+class OBox(C.Structure):
+    _fields_ = [("lo", C.c_int * 3), ("hi", C.c_int * 3)]
+
+
+class OFab(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("lo", C.c_int * 3), ("hi", C.c_int * 3), ("nc", C.c_int),
+                ("sy", C.c_long), ("sz", C.c_long), ("sn", C.c_long)]
+
+
+class OBCRec(C.Structure):
+    _fields_ = [("lo", C.c_int * 3), ("hi", C.c_int * 3)]
+
+
+BCV_NUM = 14
+
+
+class OGeom(C.Structure):
+    _fields_ = [("domain", OBox), ("per", C.c_int * 2), ("prm", C.POINTER(Params)), ("bcs", OBCRec * BCV_NUM),
+                ("extdir", (C.c_double * 6) * BCV_NUM)]
+
+
+def obox(lo, hi):
+    b = OBox()
+    for d in range(3):
+        b.lo[d] = lo[d]
+        b.hi[d] = hi[d]
+    return b
+
+
+def ofab(arr, lo):
+    """Fab over a C-contiguous float64 numpy array [comp, k, j, i] whose first element has index lo (the array stays owned by numpy)."""
+    assert arr.dtype == np.float64 and arr.flags["C_CONTIGUOUS"] and arr.ndim == 4
+    nc, nk, nj, ni = arr.shape
+    f = OFab()
+    f.p = arr.ctypes.data
+    for d, (l, n) in enumerate(zip(lo, (ni, nj, nk))):
+        f.lo[d] = l
+        f.hi[d] = l + n - 1
+    f.nc = nc
+    f.sy = ni
+    f.sz = ni * nj
+    f.sn = ni * nj * nk
+    return f
+
+
+def geom(case):
+    """Geom of a case's domain (periodicity and the SolverChoice flags the leaves read); the Params object must stay alive."""
+    p = make_params(case)
+    g = OGeom()
+    nx, ny, nz = case["ncell"]
+    g.domain = obox((0, 0, 0), (nx - 1, ny - 1, nz - 1))
+    g.per[0], g.per[1] = case["periodic"]
+    g.prm = C.pointer(p)
+    g._keep = p
+    return g
+
+
+_G = C.POINTER(OGeom)
+_F = OFab
+_B = OBox
+LEAVES = {
+    "o_omega": [_B] + [_F] * 5 + [C.c_int],
+    "o_prestep_t_advection": [_G, _B, _B] + [_F] * 15 + [C.c_int] * 4 + [C.c_double],
+    "o_prestep_diffusion": [_G, _B, _B, C.c_int, C.c_int] + [_F] * 12 + [C.c_int] * 6 + [C.c_double, C.c_double],
+    "o_coriolis": [_B, _B] + [_F] * 6 + [C.c_int, C.c_int],
+    "o_rhs_uv_3d": [_G, _B, _B] + [_F] * 16 + [C.c_int, C.c_int],
+    "o_uv3dmix": [_B, _B] + [_F] * 12 + [C.c_int, C.c_int, C.c_double],
+    "o_vert_visc_3d": [_B, C.c_int, C.c_int] + [_F] * 9 + [C.c_int, C.c_int, C.c_double],
+    "o_vert_mean_3d": [_B, C.c_int, C.c_int] + [_F] * 7 + [C.c_int, C.c_int],
+    "o_update_massflux_3d": [_G, _B, C.c_int, C.c_int] + [_F] * 10 + [C.c_int],
+    "o_rhs_t_3d": [_G, _B, _B] + [_F] * 11 + [C.c_int] * 3 + [C.c_double],
+    "o_rhs_uv_2d": [_G, _B, _B] + [_F] * 6 + [C.c_int],
+}
+
+
+def leaf(name):
+    f = getattr(lib(), name)
+    f.argtypes = LEAVES[name]
+    f.restype = None
+    return f

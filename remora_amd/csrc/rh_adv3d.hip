@@ -33,29 +33,34 @@ __device__ __forceinline__ double a3_tflux_w(const A4 &t, int i, int j, int kk, 
 // REMORA::stretch_transform, Utils/REMORA_DepthStretchTransform.H:12-249 (Vtransform 2): z_w, z_r, Hz and h comp 1 from h
 // and Zt_avg1.  The stretching curves sc/Cs depend on k alone and come from the table built in rh_create; the
 // reference evaluates cosh/exp at every (i,j,k).  sc = [sc_w | Cs_w | sc_r | Cs_r], each nz+1 long.
+// No level depends on another: one thread per (i, j, k), grid.z walks k, so every block streams one plane of each output (a column
+// per thread walking k wrote three 34-MB-strided streams per thread and ran at 3.1 TB/s; write-only kernels reach 6.4).  Level k
+// forms z_w(k), z_r(k) and Hz(k) = z_w(k+1) - z_w(k): z_w(k+1) is evaluated a second time by the thread of level k+1 with the same
+// expression on the same operands, hence the same bits as the reference's difference of the two stored values.  The top level
+// k = nz only has z_w.
+__device__ __forceinline__ double stretch_zw(int k, int nz, double zt, double hwater, double hinv, double hc, const double *__restrict__ sc_w, const double *__restrict__ Cs_w)
+{
+    if (k == nz) return zt;
+    const double cff_w = hc * sc_w[k], cff1_w = Cs_w[k];
+    const double cff2_w = (cff_w + cff1_w * hwater) * hinv;
+    return zt + (zt + hwater) * cff2_w;
+}
 __global__ void k_stretch(B3 b, A4 z_w, A4 z_r, A4 Hz, A4 h, A4 Zt, const double *__restrict__ sc, int nz, double hc)
 {
     RH_IJ(b); if (!inb2(b, i, j)) return;
+    const int k = RH_KZ;                                   // 0 .. nz
     const double *sc_w = sc, *Cs_w = sc + (nz + 1), *sc_r = sc + 2 * (nz + 1), *Cs_r = sc + 3 * (nz + 1);
     const double hwater = h(i, j, 0, 0);
     const double hinv = 1.0 / (hc + hwater);
     const double zt = Zt(i, j, 0);
-    double zw_prev = 0.0;
-    for (int k = 0; k <= nz; k++) {
-        const double cff_w = hc * sc_w[k], cff1_w = Cs_w[k];
-        const double cff2_w = (cff_w + cff1_w * hwater) * hinv;
-        double zw;
-        if (k == nz) zw = zt;
-        else zw = zt + (zt + hwater) * cff2_w;
-        if (k == 0) h(i, j, 0, 1) = zw;
-        z_w(i, j, k) = zw;
-        if (k != nz) {
-            const double cff_r = hc * sc_r[k], cff1_r = Cs_r[k];
-            const double cff2_r = (cff_r + cff1_r * hwater) * hinv;
-            z_r(i, j, k) = zt + (zt + hwater) * cff2_r;
-        }
-        if (k > 0) Hz(i, j, k - 1) = zw - zw_prev;
-        zw_prev = zw;
+    const double zw = stretch_zw(k, nz, zt, hwater, hinv, hc, sc_w, Cs_w);
+    if (k == 0) h(i, j, 0, 1) = zw;
+    z_w(i, j, k) = zw;
+    if (k != nz) {
+        const double cff_r = hc * sc_r[k], cff1_r = Cs_r[k];
+        const double cff2_r = (cff_r + cff1_r * hwater) * hinv;
+        z_r(i, j, k) = zt + (zt + hwater) * cff2_r;
+        Hz(i, j, k) = stretch_zw(k + 1, nz, zt, hwater, hinv, hc, sc_w, Cs_w) - zw;
     }
 }
 extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
@@ -68,7 +73,8 @@ extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
     RH_NEED(s->z_w, bw); RH_NEED(s->z_r, b); RH_NEED(s->Hz, b); RH_NEED(s->h, b2); RH_NEED(s->Zt_avg1, b2);
     if (s->h.ncomp < 2) return rh_fail("rh_stretch_transform: h needs 2 components");
     const double hc = -std::min(c->prm.prob_hi[2], -c->prm.tcline);                          // :51
-    k_stretch<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(s->z_w), mkA(s->z_r), mkA(s->Hz), mkA(s->h), mkA(s->Zt_avg1), c->d_sc, nz, hc);
+    dim3 gs = grid2(b); gs.z = (unsigned)(nz + 1);
+    k_stretch<<<gs, rh_block(), 0, c->stream>>>(mkB(b), mkA(s->z_w), mkA(s->z_r), mkA(s->Hz), mkA(s->h), mkA(s->Zt_avg1), c->d_sc, nz, hc);
     RH_LAUNCH_CHECK();
     BcScope xs(c);                                                                           // one message per neighbour for the three
     RH_TRY(halo_fill_boundary(c, mfv(c, s->z_w, 0, 0, 1), 0, 1));                            // :198-201
@@ -416,10 +422,13 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
     if (act)
         for (int k = 0; k <= N; k++) { double x = sX[k * 64]; x -= DCm; x *= m; phi(i, j, k) = x; }
 }
-static inline bool vv_reg_depth(int nz) { return nz == 13 || nz == 16 || nz == 50; }
+static inline bool vv_reg_depth(int nz) { return nz == 13 || nz == 16 || nz == 50 || nz == 64; }
 #define VV_D_T 16      // ring depth, tracers (3 loads per level)
 #define VV_D_V 10      // ring depth, v (6 loads per level)
 #define VV_D_U 14      // ring depth, u (4 loads per level: the i-1 operands come from the neighbouring lane)
+// ring depths of the register solver: at 64 levels (BASELINE.json configs[4]) cf / dc / ak alone take 384 of the 512 registers a lane
+// has at one wave per SIMD, so the ring shrinks to what still fits without scratch spills
+template <int NZ> struct VVD { static constexpr int T = NZ > 50 ? 8 : VV_D_T, V = NZ > 50 ? 5 : VV_D_V, U = NZ > 50 ? 7 : VV_D_U; };
 
 extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 phi, rh_array4 Hz, rh_array4 Akv, int N, double dt)
 {
@@ -440,10 +449,10 @@ extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_
         const size_t lds_reg = sizeof(double) * 2 * (size_t)(N + 1) * 64;
         if (vv_reg_depth(N + 1) && !c->noregsolve) {     // a depth the register form is built for: no operand is read twice
 #define RH_VVR(NZ) do { \
-            if (ioff) k_column_solver_reg<1, 0, 0, VV_D_U, NZ><<<gridu, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); \
-            else if (joff) k_column_solver_reg<0, 1, 0, VV_D_V, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); \
-            else k_column_solver_reg<0, 0, 0, VV_D_T, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); } while (0)
-            switch (N + 1) { case 13: RH_VVR(13); break; case 16: RH_VVR(16); break; default: RH_VVR(50); break; }
+            if (ioff) k_column_solver_reg<1, 0, 0, VVD<NZ>::U, NZ><<<gridu, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); \
+            else if (joff) k_column_solver_reg<0, 1, 0, VVD<NZ>::V, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); \
+            else k_column_solver_reg<0, 0, 0, VVD<NZ>::T, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); } while (0)
+            switch (N + 1) { case 13: RH_VVR(13); break; case 16: RH_VVR(16); break; case 64: RH_VVR(64); break; default: RH_VVR(50); break; }
 #undef RH_VVR
         }
         else if (ioff) k_column_solver<1, 0, 0, VV_D_U><<<gridu, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
@@ -477,17 +486,17 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     const dim3 gx((xbx.hi[0] - xbx.lo[0] + 63) / 63, xbx.hi[1] - xbx.lo[1] + 1, 1), gy((ybx.hi[0] - ybx.lo[0] + 64) / 64, ybx.hi[1] - ybx.lo[1] + 1, 1);
     const bool reg = vv_reg_depth(N + 1) && !c->noregsolve;
     const size_t lds_reg = sizeof(double) * 2 * (size_t)(N + 1) * 64;
-#define RH_VVU(NZ) k_column_solver_reg<1, 0, 1, VV_D_U, NZ><<<gx, 64, lds_reg, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn), \
+#define RH_VVU(NZ) k_column_solver_reg<1, 0, 1, VVD<NZ>::U, NZ><<<gx, 64, lds_reg, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn), \
         mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab)
-#define RH_VVV(NZ) k_column_solver_reg<0, 1, 1, VV_D_V, NZ><<<gy, 64, lds_reg, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm), \
+#define RH_VVV(NZ) k_column_solver_reg<0, 1, 1, VVD<NZ>::V, NZ><<<gy, 64, lds_reg, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm), \
         mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab)
     { TScope t(c, "uv_corrector");
-    if (reg) { switch (N + 1) { case 13: RH_VVU(13); break; case 16: RH_VVU(16); break; default: RH_VVU(50); break; } }
+    if (reg) { switch (N + 1) { case 13: RH_VVU(13); break; case 16: RH_VVU(16); break; case 64: RH_VVU(64); break; default: RH_VVU(50); break; } }
     else k_column_solver<1, 0, 1, VV_D_U><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn),
         mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab);
     RH_LAUNCH_CHECK(); }
     TScope t(c, "uv_corrector");
-    if (reg) { switch (N + 1) { case 13: RH_VVV(13); break; case 16: RH_VVV(16); break; default: RH_VVV(50); break; } }
+    if (reg) { switch (N + 1) { case 13: RH_VVV(13); break; case 16: RH_VVV(16); break; case 64: RH_VVV(64); break; default: RH_VVV(50); break; } }
     else k_column_solver<0, 1, 1, VV_D_V><<<gy, 64, lds_bytes, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm),
         mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab);
     RH_LAUNCH_CHECK();

@@ -54,3 +54,236 @@ def test_coriolis_leaf():
     assert np.array_equal(dev["ru"].cpu().numpy(), exp_ru)
     assert np.array_equal(dev["rv"].cpu().numpy(), exp_rv)
     rem.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The starred leaves through their C-ABI entry points against the oracle's restatement of the same reference lambda
+# (oracle/leaves.c, bound in oracle/oracle_py.py), on seeded random operands (seed 12345, the ranges of SURVEY.md section 8d:
+# Hz in [1, 20] m, |u| <= 0.5, T in [5, 25], Akv in [1e-5, 1e-2]); transports and W of both signs; boxes that do not fill their
+# last tile in either direction (150 = 2 x 64 + 22 columns, 21 = 2 x 8 + 5 rows).  Bit-exact.
+from oracle import oracle_py as O          # noqa: E402
+
+NX, NY = 150, 21
+
+
+class Arr:
+    """one field: host array [comp, k, j, i] with its index origin, the oracle's Fab over it and a device copy with its rh_array4"""
+
+    def __init__(self, host, lo):
+        self.h = np.ascontiguousarray(host, dtype=np.float64)
+        self.lo = tuple(lo)
+        self.d = torch.tensor(self.h, device="cuda:0")
+        self.h0 = self.h.copy()
+
+    def fab(self):
+        return O.ofab(self.h, self.lo)
+
+    def a4(self):
+        return _a4(self.d, self.lo)
+
+    def same(self):
+        return np.array_equal(self.d.cpu().numpy(), self.h)
+
+    def changed(self):
+        return not np.array_equal(self.h, self.h0)
+
+
+def _rand(rng, lo_v, hi_v, nc, nk, lo, hi):
+    """uniform field on the index box lo..hi (2-D in i, j), nk levels"""
+    return Arr(rng.uniform(lo_v, hi_v, (nc, nk, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1)), (lo[0], lo[1], 0))
+
+
+def _ctx(nz, periodic):
+    cfg = cases.get("Seamount" if periodic else "DoubleGyre")
+    cfg["ncell"] = (NX, NY, nz)
+    return cfg, REMORA(cfg)
+
+
+def _metrics(rng, g):
+    return (_rand(rng, 1e-3, 2e-3, 1, 1, (-g, -g - 1), (NX - 1 + g, NY + g)), _rand(rng, 1e-3, 2e-3, 1, 1, (-g - 1, -g), (NX + g, NY - 1 + g)))
+
+
+@pytest.mark.parametrize("periodic", [True, False])
+def test_rhs_t_3d_leaf(periodic):
+    """REMORA::rhs_t_3d, REMORA_rhs_t_3d.cpp:27-335"""
+    nz = 7; N = nz - 1
+    cfg, rem = _ctx(nz, periodic)
+    rng = np.random.default_rng(12345)
+    g = 3
+    t = _rand(rng, 5.0, 25.0, 1, nz, (-g, -g), (NX - 1 + g, NY - 1 + g)); ss = _rand(rng, 5.0, 25.0, 1, nz, (-g, -g), (NX - 1 + g, NY - 1 + g))
+    Huon = _rand(rng, -50.0, 50.0, 1, nz, (-g, -g), (NX + g, NY - 1 + g)); Hvom = _rand(rng, -50.0, 50.0, 1, nz, (-g, -g), (NX - 1 + g, NY + g))
+    Hz = _rand(rng, 1.0, 20.0, 1, nz, (-g, -g), (NX - 1 + g, NY - 1 + g)); W = _rand(rng, -5.0, 5.0, 1, nz + 1, (-g, -g), (NX - 1 + g, NY - 1 + g))
+    pm, pn = _metrics(rng, g)
+    msku = Arr(np.ones((1, 1, NY + 2 * g, NX + 1 + 2 * g)), (-g, -g, 0)); mskv = Arr(np.ones((1, 1, NY + 1 + 2 * g, NX + 2 * g)), (-g, -g, 0))
+    FC = Arr(np.zeros((1, nz + 1, NY + 2 * g, NX + 2 * g)), (-g, -g, 0))
+    dt = 300.0
+    bx = ((0, 0, 0), (NX - 1, NY - 1, N))
+    O.leaf("o_rhs_t_3d")(O.geom(cfg), O.obox(*bx), O.obox((-g, -g, 0), (NX - 1 + g, NY - 1 + g, N)), t.fab(), ss.fab(), Huon.fab(), Hvom.fab(), Hz.fab(),
+                         pn.fab(), pm.fab(), W.fab(), FC.fab(), msku.fab(), mskv.fab(), 0, 0, N, dt)
+    L.check(rem.lib.rh_rhs_t_3d(rem.ctx, L.box(*bx), t.a4(), ss.a4(), Huon.a4(), Hvom.a4(), Hz.a4(), pn.a4(), pm.a4(), W.a4(), msku.a4(), mskv.a4(), N, dt))
+    rem.sync()
+    assert t.changed() and t.same()
+    rem.close()
+
+
+@pytest.mark.parametrize("periodic", [True, False])
+def test_rhs_uv_3d_leaf(periodic):
+    """REMORA::coriolis + REMORA::rhs_uv_3d (REMORA_coriolis.cpp:10-40, REMORA_rhs_uv_3d.cpp:31-385): domain-edge curvature branches
+    with walls, none with periodic sides"""
+    nz = 7; N = nz - 1
+    cfg, rem = _ctx(nz, periodic)
+    rng = np.random.default_rng(12345)
+    g = 3
+    cb = ((-g, -g), (NX - 1 + g, NY - 1 + g)); ub = ((-g, -g), (NX + g, NY - 1 + g)); vb = ((-g, -g), (NX - 1 + g, NY + g))
+    uold = _rand(rng, -0.5, 0.5, 1, nz, *ub); vold = _rand(rng, -0.5, 0.5, 1, nz, *vb)
+    ru = _rand(rng, -1.0, 1.0, 2, nz, *ub); rv = _rand(rng, -1.0, 1.0, 2, nz, *vb)
+    rufrc = _rand(rng, -1.0, 1.0, 2, 1, *ub); rvfrc = _rand(rng, -1.0, 1.0, 2, 1, *vb)
+    sustr = _rand(rng, -1e-4, 1e-4, 1, 1, *ub); svstr = _rand(rng, -1e-4, 1e-4, 1, 1, *vb)
+    bustr = _rand(rng, -1e-4, 1e-4, 1, 1, *ub); bvstr = _rand(rng, -1e-4, 1e-4, 1, 1, *vb)
+    Huon = _rand(rng, -50.0, 50.0, 1, nz, *ub); Hvom = _rand(rng, -50.0, 50.0, 1, nz, *vb)
+    W = _rand(rng, -5.0, 5.0, 1, nz + 1, *cb); Hz = _rand(rng, 1.0, 20.0, 1, nz, *cb)
+    pm = _rand(rng, 1e-3, 2e-3, 1, 1, *cb); pn = _rand(rng, 1e-3, 2e-3, 1, 1, *cb); fcor = _rand(rng, -1e-4, 1e-4, 1, 1, *cb)
+    fomn = Arr(fcor.h * (1.0 / (pm.h * pn.h)), fcor.lo)                       # REMORA_setup_step.cpp:233-239
+    FC = Arr(np.zeros((1, nz + 1, NY + 1 + 2 * g, NX + 1 + 2 * g)), (-g, -g, 0))
+    xbx = ((0, 0, 0), (NX, NY - 1, N)); ybx = ((0, 0, 0), (NX - 1, NY, N))
+    use_cor = 1
+    O.leaf("o_coriolis")(O.obox(*xbx), O.obox(*ybx), uold.fab(), vold.fab(), ru.fab(), rv.fab(), Hz.fab(), fomn.fab(), 0, 0)
+    O.leaf("o_rhs_uv_3d")(O.geom(cfg), O.obox(*xbx), O.obox(*ybx), uold.fab(), vold.fab(), ru.fab(), rv.fab(), rufrc.fab(), rvfrc.fab(), sustr.fab(), svstr.fab(),
+                          bustr.fab(), bvstr.fab(), Huon.fab(), Hvom.fab(), pm.fab(), pn.fab(), W.fab(), FC.fab(), 0, N)
+    L.check(rem.lib.rh_rhs_uv_3d(rem.ctx, L.box(*xbx), L.box(*ybx), uold.a4(), vold.a4(), ru.a4(), rv.a4(), rufrc.a4(), rvfrc.a4(), sustr.a4(), svstr.a4(),
+                                 bustr.a4(), bvstr.a4(), Huon.a4(), Hvom.a4(), pm.a4(), pn.a4(), W.a4(), Hz.a4(), fcor.a4(), use_cor, 0, N))
+    rem.sync()
+    for a in (ru, rv, rufrc, rvfrc):
+        assert a.changed() and a.same()
+    rem.close()
+
+
+def test_uv3dmix_leaf():
+    """REMORA::uv3dmix, REMORA_uv3dmix.cpp:6-149 (3-D call)"""
+    nz = 7; N = nz - 1
+    cfg, rem = _ctx(nz, False)
+    rng = np.random.default_rng(12345)
+    g = 3
+    cb = ((-g, -g), (NX - 1 + g, NY - 1 + g)); ub = ((-g, -g), (NX + g, NY - 1 + g)); vb = ((-g, -g), (NX - 1 + g, NY + g)); pb = ((-g, -g), (NX + g, NY + g))
+    u = _rand(rng, -0.5, 0.5, 1, nz, *ub); v = _rand(rng, -0.5, 0.5, 1, nz, *vb)
+    uold = _rand(rng, -0.5, 0.5, 1, nz, *ub); vold = _rand(rng, -0.5, 0.5, 1, nz, *vb)
+    rufrc = _rand(rng, -1.0, 1.0, 2, 1, *ub); rvfrc = _rand(rng, -1.0, 1.0, 2, 1, *vb)
+    visc2_p = _rand(rng, 1.0, 100.0, 1, 2, *pb); visc2_r = _rand(rng, 1.0, 100.0, 1, 2, *cb)
+    Hz = _rand(rng, 1.0, 20.0, 1, nz, *cb)
+    pm = _rand(rng, 1e-3, 2e-3, 1, 1, (-g - 1, -g - 1), (NX + g, NY + g)); pn = _rand(rng, 1e-3, 2e-3, 1, 1, (-g - 1, -g - 1), (NX + g, NY + g))
+    mskp = Arr(np.ones((1, 1, NY + 1 + 2 * g, NX + 1 + 2 * g)), (-g, -g, 0))
+    xbx = ((0, 0, 0), (NX, NY - 1, N)); ybx = ((0, 0, 0), (NX - 1, NY, N))
+    dt = 300.0
+    O.leaf("o_uv3dmix")(O.obox(*xbx), O.obox(*ybx), u.fab(), v.fab(), uold.fab(), vold.fab(), rufrc.fab(), rvfrc.fab(), visc2_p.fab(), visc2_r.fab(), Hz.fab(),
+                        pm.fab(), pn.fab(), mskp.fab(), 0, 0, dt)
+    L.check(rem.lib.rh_uv3dmix(rem.ctx, L.box(*xbx), L.box(*ybx), u.a4(), v.a4(), uold.a4(), vold.a4(), rufrc.a4(), rvfrc.a4(), visc2_p.a4(), visc2_r.a4(),
+                               Hz.a4(), pm.a4(), pn.a4(), mskp.a4(), 0, 0, dt))
+    rem.sync()
+    for a in (u, v, rufrc, rvfrc):
+        assert a.changed() and a.same()
+    rem.close()
+
+
+@pytest.mark.parametrize("nz", [7, 16])          # 7: LDS-ring solver, 16: register-resident solver
+@pytest.mark.parametrize("ioff,joff", [(0, 0), (1, 0), (0, 1)])
+def test_vert_visc_3d_leaf(nz, ioff, joff):
+    """REMORA::vert_visc_3d, REMORA_vert_visc_3d.cpp:10-107: tracer, u and v forms"""
+    N = nz - 1
+    cfg, rem = _ctx(nz, True)
+    rng = np.random.default_rng(12345)
+    g = 2
+    hi = (NX - 1 + ioff, NY - 1 + joff)
+    fb = ((-g, -g), (hi[0] + g, hi[1] + g))
+    phi = _rand(rng, 5.0, 25.0, 1, nz, *fb); Hz = _rand(rng, 1.0, 20.0, 1, nz, *fb); Akv = _rand(rng, 1e-5, 1e-2, 1, nz + 1, *fb)
+    scr = [Arr(np.zeros((1, nz + 2, hi[1] + 1 + 2 * g, hi[0] + 1 + 2 * g)), (-g, -g, 0)) for _ in range(6)]       # Hzk, AK, BC, DC, FC, CF
+    bx = ((0, 0, 0), (hi[0], hi[1], N))
+    dt = 300.0
+    O.leaf("o_vert_visc_3d")(O.obox(*bx), ioff, joff, phi.fab(), Hz.fab(), scr[0].fab(), scr[1].fab(), Akv.fab(), scr[2].fab(), scr[3].fab(), scr[4].fab(),
+                             scr[5].fab(), 0, N, dt)
+    L.check(rem.lib.rh_vert_visc_3d(rem.ctx, L.box(*bx), ioff, joff, phi.a4(), Hz.a4(), Akv.a4(), N, dt))
+    rem.sync()
+    assert phi.changed() and phi.same()
+    rem.close()
+
+
+@pytest.mark.parametrize("periodic", [True, False])
+def test_rhs_uv_2d_leaf(periodic):
+    """REMORA::rhs_uv_2d, REMORA_rhs_uv_2d.cpp:20-238 (the entry point the fused barotropic kernel never calls)"""
+    cfg, rem = _ctx(7, periodic)
+    rng = np.random.default_rng(12345)
+    g = 3
+    ub = ((-g, -g), (NX + g, NY - 1 + g)); vb = ((-g, -g), (NX - 1 + g, NY + g))
+    ubar = _rand(rng, -0.5, 0.5, 3, 1, *ub); vbar = _rand(rng, -0.5, 0.5, 3, 1, *vb)
+    rhs_u = _rand(rng, -1.0, 1.0, 1, 1, *ub); rhs_v = _rand(rng, -1.0, 1.0, 1, 1, *vb)
+    DUon = _rand(rng, -500.0, 500.0, 1, 1, *ub); DVom = _rand(rng, -500.0, 500.0, 1, 1, *vb)
+    xbx = ((0, 0, 0), (NX, NY - 1, 0)); ybx = ((0, 0, 0), (NX - 1, NY, 0))
+    for krhs in (0, 2):
+        O.leaf("o_rhs_uv_2d")(O.geom(cfg), O.obox(*xbx), O.obox(*ybx), ubar.fab(), vbar.fab(), rhs_u.fab(), rhs_v.fab(), DUon.fab(), DVom.fab(), krhs)
+        L.check(rem.lib.rh_rhs_uv_2d(rem.ctx, L.box(*xbx), L.box(*ybx), ubar.a4(), vbar.a4(), rhs_u.a4(), rhs_v.a4(), DUon.a4(), DVom.a4(), krhs))
+        rem.sync()
+        assert rhs_u.changed() and rhs_u.same() and rhs_v.same()
+    rem.close()
+
+
+@pytest.mark.parametrize("periodic", [True, False])
+@pytest.mark.parametrize("ioff,joff", [(1, 0), (0, 1)])
+def test_update_massflux_3d_leaf(periodic, ioff, joff):
+    """REMORA::update_massflux_3d, REMORA_update_massflux_3d.cpp:24-122, on the grow-2 box the driver uses (walls: the boundary-face
+    velocity correction of :87-101)"""
+    nz = 7; N = nz - 1
+    cfg, rem = _ctx(nz, periodic)
+    rng = np.random.default_rng(12345)
+    g = 3
+    fb = ((-g, -g), (NX - 1 + ioff + g, NY - 1 + joff + g)); cb = ((-g, -g), (NX - 1 + g, NY - 1 + g))
+    phi = _rand(rng, -0.5, 0.5, 1, nz, *fb); Hphi = _rand(rng, -50.0, 50.0, 1, nz, *fb); Hz = _rand(rng, 1.0, 20.0, 1, nz, *cb)
+    phibar = _rand(rng, -0.5, 0.5, 3, 1, *fb); pmn = _rand(rng, 1e-3, 2e-3, 1, 1, (-g - 1, -g - 1), (NX + g, NY + g))
+    a1 = _rand(rng, -500.0, 500.0, 1, 1, *fb); a2 = _rand(rng, -500.0, 500.0, 1, 1, *fb)
+    msk = Arr(np.ones((1, 1, fb[1][1] + g + 1, fb[1][0] + g + 1)), (-g, -g, 0))
+    DC = Arr(np.zeros((1, nz + 2, fb[1][1] + g + 1, fb[1][0] + g + 1)), (-g, -g, -1)); FC = Arr(np.zeros((1, nz + 1, fb[1][1] + g + 1, fb[1][0] + g + 1)), (-g, -g, 0))
+    DC.lo = (-g, -g, -1)
+    bx = ((-2, -2, 0), (NX - 1 + 2, NY - 1 + 2, N))
+    O.leaf("o_update_massflux_3d")(O.geom(cfg), O.obox(*bx), ioff, joff, phi.fab(), phibar.fab(), Hphi.fab(), Hz.fab(), pmn.fab(), a1.fab(), a2.fab(),
+                                   DC.fab(), FC.fab(), msk.fab(), 0)
+    L.check(rem.lib.rh_update_massflux_3d(rem.ctx, L.box(*bx), ioff, joff, phi.a4(), phibar.a4(), Hphi.a4(), Hz.a4(), pmn.a4(), a1.a4(), a2.a4(), msk.a4(), N))
+    rem.sync()
+    assert Hphi.changed() and Hphi.same() and phibar.same() and phi.same()
+    if not periodic:
+        assert phi.changed()
+    rem.close()
+
+
+def test_prestep_t_leaf():
+    """omega + REMORA::prestep_t_advection + the tracer call of prestep_diffusion (REMORA_prestep_t_advection.cpp:10-361,
+    REMORA_prestep_diffusion.cpp:19-165 with lambda = 1) for one tracer, second-and-later-step weights (iic = 2)"""
+    nz = 7; N = nz - 1
+    cfg, rem = _ctx(nz, True)
+    rng = np.random.default_rng(12345)
+    g = 3
+    cb = ((-g, -g), (NX - 1 + g, NY - 1 + g)); ub = ((-g, -g), (NX + g, NY - 1 + g)); vb = ((-g, -g), (NX - 1 + g, NY + g))
+    told = _rand(rng, 5.0, 25.0, 1, nz, *cb); tnew = _rand(rng, 5.0, 25.0, 1, nz, *cb); sst = _rand(rng, 0.0, 1.0, 1, nz, *cb)
+    cache = Arr(tnew.h.copy(), tnew.lo)
+    Hz = _rand(rng, 1.0, 20.0, 1, nz, *cb); Huon = _rand(rng, -50.0, 50.0, 1, nz, *ub); Hvom = _rand(rng, -50.0, 50.0, 1, nz, *vb)
+    z_w = Arr(np.cumsum(np.concatenate([np.full((1, 1) + Hz.h.shape[2:], -200.0), Hz.h], axis=1), axis=1), Hz.lo)
+    z_r = Arr(0.5 * (z_w.h[:, 1:] + z_w.h[:, :-1]), Hz.lo)
+    h = Arr(np.repeat(-z_w.h[:, :1], 2, axis=0), Hz.lo)
+    W = Arr(np.zeros((1, nz + 1) + Hz.h.shape[2:]), Hz.lo)
+    pm, pn = (_rand(rng, 1e-3, 2e-3, 1, 1, *cb), _rand(rng, 1e-3, 2e-3, 1, 1, *cb))
+    msku = Arr(np.ones((1, 1, NY + 2 * g, NX + 1 + 2 * g)), (-g, -g, 0)); mskv = Arr(np.ones((1, 1, NY + 1 + 2 * g, NX + 2 * g)), (-g, -g, 0))
+    Akt = _rand(rng, 1e-5, 1e-2, 3, nz + 1, *cb); ru = _rand(rng, -1.0, 1.0, 2, nz, *ub)
+    zero2 = Arr(np.zeros((1, 1) + Hz.h.shape[2:]), Hz.lo)
+    DC = Arr(np.zeros((1, nz + 2) + Hz.h.shape[2:]), (-g, -g, -1)); FC = Arr(np.zeros((1, nz + 2) + Hz.h.shape[2:]), Hz.lo)
+    dt = 300.0; iic = 2
+    bx = ((0, 0, 0), (NX - 1, NY - 1, N)); gbx = ((-g, -g, -3), (NX - 1 + g, NY - 1 + g, N + 3))
+    geo = O.geom(cfg)
+    O.leaf("o_prestep_t_advection")(geo, O.obox(*bx), O.obox(*gbx), told.fab(), cache.fab(), Hz.fab(), Huon.fab(), Hvom.fab(), W.fab(), DC.fab(), FC.fab(),
+                                    sst.fab(), z_w.fab(), h.fab(), pm.fab(), pn.fab(), msku.fab(), mskv.fab(), iic, 0, 0, N, dt)
+    O.leaf("o_prestep_diffusion")(geo, O.obox(*bx), O.obox(*gbx), 0, 0, tnew.fab(), told.fab(), ru.fab(), Hz.fab(), Akt.fab(), DC.fab(), FC.fab(),
+                                  zero2.fab(), zero2.fab(), z_r.fab(), pm.fab(), pn.fab(), iic, iic, 0, 0, 0, N, 1.0, dt)
+    g1 = ((-1, -1, 0), (NX, NY, N))
+    L.check(rem.lib.rh_omega(rem.ctx, L.box(*g1), W.a4(), Huon.a4(), Hvom.a4(), z_w.a4(), h.a4(), N))
+    L.check(rem.lib.rh_prestep_t(rem.ctx, L.box(*bx), told.a4(), tnew.a4(), sst.a4(), Hz.a4(), Huon.a4(), Hvom.a4(), W.a4(), pm.a4(), pn.a4(),
+                                 msku.a4(), mskv.a4(), iic, 0, N, dt))
+    rem.sync()
+    assert W.changed() and W.same()
+    assert sst.changed() and sst.same() and tnew.changed() and tnew.same()
+    rem.close()

@@ -196,10 +196,10 @@ def test_reductions_against_oracle(case):
     rem.close(); orc.close()
 
 
-@pytest.mark.parametrize("nz", [50, 64, 20])
+@pytest.mark.parametrize("nz", [50, 64, 20, 70])
 def test_deep_columns_against_oracle(nz):
-    """The column kernels pick their form by depth: register-resident solver for the depths it is built for (13, 16, 50), LDS ring
-    kernel otherwise, with the dynamic-LDS opt-in above 62 levels (nz = 64 is the depth of BASELINE configs[4]).  Seamount physics
+    """The column kernels pick their form by depth: register-resident solver for the depths it is built for (13, 16, 50 and 64, the depth of BASELINE
+    configs[4]), LDS ring kernel otherwise (20), with the dynamic-LDS opt-in above 62 levels (70).  Seamount physics
     (steep bathymetry, no device transcendental: bit-exact) on its own horizontal grid with nz levels, three steps, all fields."""
     cfg = cases.get("Seamount")
     cfg["ncell"] = (cfg["ncell"][0], cfg["ncell"][1], nz)
