@@ -33,34 +33,55 @@ __device__ __forceinline__ double a3_tflux_w(const A4 &t, int i, int j, int kk, 
 // REMORA::stretch_transform, Utils/REMORA_DepthStretchTransform.H:12-249 (Vtransform 2): z_w, z_r, Hz and h comp 1 from h
 // and Zt_avg1.  The stretching curves sc/Cs depend on k alone and come from the table built in rh_create; the
 // reference evaluates cosh/exp at every (i,j,k).  sc = [sc_w | Cs_w | sc_r | Cs_r], each nz+1 long.
-// No level depends on another: one thread per (i, j, k), grid.z walks k, so every block streams one plane of each output (a column
-// per thread walking k wrote three 34-MB-strided streams per thread and ran at 3.1 TB/s; write-only kernels reach 6.4).  Level k
-// forms z_w(k), z_r(k) and Hz(k) = z_w(k+1) - z_w(k): z_w(k+1) is evaluated a second time by the thread of level k+1 with the same
-// expression on the same operands, hence the same bits as the reference's difference of the two stored values.  The top level
-// k = nz only has z_w.
-__device__ __forceinline__ double stretch_zw(int k, int nz, double zt, double hwater, double hinv, double hc, const double *__restrict__ sc_w, const double *__restrict__ Cs_w)
+// No level depends on another: one thread per (i, j) and ST_KC levels, grid.z walks k, so every block streams a few planes of each
+// output (a column per thread walking all of k wrote three 34-MB-strided streams per thread).  Level k forms z_w(k), z_r(k) and
+// Hz(k) = z_w(k+1) - z_w(k); z_w(k+1) at the top of a thread's range is evaluated again by the thread that owns it, with the same
+// expression on the same operands, hence the same bits as the reference's difference of the two stored values.  Level nz only has z_w.
+// ST_KC levels per thread.  One level per thread was latency-bound, not bandwidth-bound (PMC: 5.9 GB moved in 1.61 ms): a wave waited
+// for its two 2-D loads and for a chain of scalar table loads before its first store, and 32 resident waves per CU with 1.5 KB of
+// stores each cannot cover that.  Here a wave stores 12 KB, and the four stretching curves of the block's levels are staged in LDS by
+// one vector load per table entry instead of 4 x (ST_KC + 1) dependent scalar loads.
+#define ST_KC 8
+__global__ void __launch_bounds__(RH_BX * RH_BY)
+k_stretch(B3 b, A4 z_w, A4 z_r, A4 Hz, A4 h, A4 Zt, const double *__restrict__ sc, int nz, double hc)
 {
-    if (k == nz) return zt;
-    const double cff_w = hc * sc_w[k], cff1_w = Cs_w[k];
-    const double cff2_w = (cff_w + cff1_w * hwater) * hinv;
-    return zt + (zt + hwater) * cff2_w;
-}
-__global__ void k_stretch(B3 b, A4 z_w, A4 z_r, A4 Hz, A4 h, A4 Zt, const double *__restrict__ sc, int nz, double hc)
-{
-    RH_IJ(b); if (!inb2(b, i, j)) return;
-    const int k = RH_KZ;                                   // 0 .. nz
-    const double *sc_w = sc, *Cs_w = sc + (nz + 1), *sc_r = sc + 2 * (nz + 1), *Cs_r = sc + 3 * (nz + 1);
-    const double hwater = h(i, j, 0, 0);
+    __shared__ double tab[4 * (ST_KC + 1)];                // sc_w, Cs_w, sc_r, Cs_r of levels k0 .. k0 + ST_KC
+    const RhTile rh_t_ = rh_tile();
+    const int i = b.lo0 + rh_t_.x * RH_BX + (int)threadIdx.x, j = b.lo1 + rh_t_.y * RH_BY + (int)threadIdx.y;
+    const int k0 = rh_t_.z * ST_KC;                        // levels k0 .. k0 + ST_KC - 1 of 0 .. nz
+    const int tid = (int)threadIdx.y * RH_BX + (int)threadIdx.x;
+    if (tid < 4 * (ST_KC + 1)) {
+        const int t = tid / (ST_KC + 1), q = tid - t * (ST_KC + 1), k = k0 + q;
+        tab[tid] = sc[t * (nz + 1) + (k <= nz ? k : nz)];
+    }
+    const bool in = inb2(b, i, j);
+    double hwater = 1.0, zt = 0.0;
+    if (in) { hwater = h(i, j, 0, 0); zt = Zt(i, j, 0); }
+    __syncthreads();
+    if (!in) return;
+    const double *sc_w = tab, *Cs_w = tab + (ST_KC + 1), *sc_r = tab + 2 * (ST_KC + 1), *Cs_r = tab + 3 * (ST_KC + 1);
     const double hinv = 1.0 / (hc + hwater);
-    const double zt = Zt(i, j, 0);
-    const double zw = stretch_zw(k, nz, zt, hwater, hinv, hc, sc_w, Cs_w);
-    if (k == 0) h(i, j, 0, 1) = zw;
-    z_w(i, j, k) = zw;
-    if (k != nz) {
-        const double cff_r = hc * sc_r[k], cff1_r = Cs_r[k];
-        const double cff2_r = (cff_r + cff1_r * hwater) * hinv;
-        z_r(i, j, k) = zt + (zt + hwater) * cff2_r;
-        Hz(i, j, k) = stretch_zw(k + 1, nz, zt, hwater, hinv, hc, sc_w, Cs_w) - zw;
+    auto zw_at = [&](int q) -> double {                   // z_w of level k0 + q, :63-188 (the same expression for every level: same bits as stretch_zw)
+        if (k0 + q == nz) return zt;
+        const double cff_w = hc * sc_w[q], cff1_w = Cs_w[q];
+        const double cff2_w = (cff_w + cff1_w * hwater) * hinv;
+        return zt + (zt + hwater) * cff2_w;
+    };
+    double zw = zw_at(0);
+#pragma unroll
+    for (int q = 0; q < ST_KC; q++) {
+        const int k = k0 + q;
+        if (k > nz) break;
+        if (k == 0) h(i, j, 0, 1) = zw;
+        z_w(i, j, k) = zw;
+        if (k != nz) {
+            const double cff_r = hc * sc_r[q], cff1_r = Cs_r[q];
+            const double cff2_r = (cff_r + cff1_r * hwater) * hinv;
+            z_r(i, j, k) = zt + (zt + hwater) * cff2_r;
+            const double zw_up = zw_at(q + 1);
+            Hz(i, j, k) = zw_up - zw;
+            zw = zw_up;
+        }
     }
 }
 extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
@@ -73,7 +94,7 @@ extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
     RH_NEED(s->z_w, bw); RH_NEED(s->z_r, b); RH_NEED(s->Hz, b); RH_NEED(s->h, b2); RH_NEED(s->Zt_avg1, b2);
     if (s->h.ncomp < 2) return rh_fail("rh_stretch_transform: h needs 2 components");
     const double hc = -std::min(c->prm.prob_hi[2], -c->prm.tcline);                          // :51
-    dim3 gs = grid2(b); gs.z = (unsigned)(nz + 1);
+    dim3 gs = grid2(b); gs.z = (unsigned)((nz + 1 + ST_KC - 1) / ST_KC);
     k_stretch<<<gs, rh_block(), 0, c->stream>>>(mkB(b), mkA(s->z_w), mkA(s->z_r), mkA(s->Hz), mkA(s->h), mkA(s->Zt_avg1), c->d_sc, nz, hc);
     RH_LAUNCH_CHECK();
     BcScope xs(c);                                                                           // one message per neighbour for the three

@@ -346,13 +346,62 @@ struct B2v { int lo0, lo1, hi0, hi1; };      // the rank's valid cell box; every
 // output pointers, shapes, the time-stepping weights -- was parked in vector lanes across the whole kernel.  The kernel therefore
 // takes ONE struct and the later phases read their scalars again from the kernel-argument segment (scalar loads, served by the
 // scalar cache) through a pointer the compiler cannot trace back to the argument, so nothing has to stay live from phase to phase.
-struct K2Args { B2v vb; UVPar P; ZetaPar zp; K2Arrays A; int ghost_from_mem; };
+struct K2Args { B2v vb; UVPar P; ZetaPar zp; K2Arrays A; int ghost_from_mem; int ntile_y; };    // ntile_y: rows of the grid that are tiles; the rows above carry the ghost frame
 __device__ __forceinline__ const K2Args &k2_args_again()
 {
     typedef const K2Args __attribute__((address_space(4))) *KP;
     KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();     // the struct is the only argument: offset 0 of the segment
     asm volatile("" : "+s"(kp));
     return *(const K2Args *)kp;
+}
+// One point of the ghost frame (tbxp3 outside tbxp1), enumerated as in k2d_frame: accumulation of the time averages, :293-356.
+__device__ __forceinline__ void k2_frame_point(const K2Args &L, int g)
+{
+    const B2v &vb = L.vb; const ZetaPar &zp = L.zp; const K2Arrays &A = L.A;
+    const B3 g3{vb.lo0 - 3, vb.lo1 - 3, 0, vb.hi0 + 3, vb.hi1 + 3, 0}, t1{vb.lo0 - 1, vb.lo1 - 1, 0, vb.hi0 + 1, vb.hi1 + 1, 0};
+    const B3 xg{vb.lo0 - 2, vb.lo1 - 2, 0, vb.hi0 + 3, vb.hi1 + 2, 0}, yg{vb.lo0 - 2, vb.lo1 - 2, 0, vb.hi0 + 2, vb.hi1 + 3, 0};
+    const int NX = g3.hi0 - g3.lo0 + 1, NY = g3.hi1 - g3.lo1 + 1, vx = t1.hi0 - t1.lo0 + 1, vy = t1.hi1 - t1.lo1 + 1;
+    const int nglo_x = t1.lo0 - g3.lo0, nglo_y = t1.lo1 - g3.lo1;
+    const int nrow_part = (NY - vy) * NX, total = nrow_part + vy * (NX - vx);
+    if (g >= total) return;
+    int i, j;
+    if (g < nrow_part) { const int row = g / NX; i = g3.lo0 + g % NX; j = row < nglo_y ? g3.lo1 + row : t1.hi1 + 1 + (row - nglo_y); }
+    else { const int r = g - nrow_part, w = NX - vx, row = r / w, cc = r % w; j = t1.lo1 + row; i = cc < nglo_x ? g3.lo0 + cc : t1.hi0 + 1 + (cc - nglo_x); }
+    const V2 zeta_rhs{A.r3, A.R3[R3_ZRHS]}, h{A.r3, A.R3[R3_H]}, Zt_avg1{A.r3, A.R3[R3_ZT]}, pm{A.spm, A.pm}, pn{A.spn, A.pn};
+    const V2 ub_rhs{A.u2, A.U[FA_RHS]}, DU_avg1{A.u2, A.U[FA_AVG1]}, DU_avg2{A.u2, A.U[FA_AVG2]}, DUon_g{A.u2, A.U[FA_DON]};
+    const V2 vb_rhs{A.v2, A.V[FA_RHS]}, DV_avg1{A.v2, A.V[FA_AVG1]}, DV_avg2{A.v2, A.V[FA_AVG2]}, DVom_g{A.v2, A.V[FA_DON]};
+    const double zr = zeta_rhs(i, j, 0);
+    const double d0 = zr + h(i, j, 0);
+    const bool inx = inb2(xg, i, j), iny = inb2(yg, i, j);
+    double du = 0.0, dv = 0.0;
+    if (inx) {
+        if (L.ghost_from_mem) du = DUon_g(i, j, 0);
+        else {
+            const double on_u = 2.0 / (pn(i, j, 0) + pn(i - 1, j, 0));
+            const double cff1 = 0.5 * on_u * (d0 + (zeta_rhs(i - 1, j, 0) + h(i - 1, j, 0)));
+            du = ub_rhs(i, j, 0) * cff1;
+        }
+    }
+    if (iny) {
+        if (L.ghost_from_mem) dv = DVom_g(i, j, 0);
+        else {
+            const double om_v = 2.0 / (pm(i, j, 0) + pm(i, j - 1, 0));
+            const double cff1 = 0.5 * om_v * (d0 + (zeta_rhs(i, j - 1, 0) + h(i, j - 1, 0)));
+            dv = vb_rhs(i, j, 0) * cff1;
+        }
+    }
+    if (zp.avg_mode == 0) {
+        Zt_avg1(i, j, 0) = 0.0;
+        if (inx) { DU_avg1(i, j, 0) = 0.0; DU_avg2(i, j, 0) = zp.wt_b * du; }
+        if (iny) { DV_avg1(i, j, 0) = 0.0; DV_avg2(i, j, 0) = zp.wt_b * dv; }
+    } else if (zp.avg_mode == 1) {
+        Zt_avg1(i, j, 0) += zp.wt_a * zr;
+        if (inx) { DU_avg1(i, j, 0) += zp.wt_a * du; DU_avg2(i, j, 0) += zp.wt_b * du; }
+        if (iny) { DV_avg1(i, j, 0) += zp.wt_a * dv; DV_avg2(i, j, 0) += zp.wt_b * dv; }
+    } else {
+        if (inx) DU_avg2(i, j, 0) = DU_avg2(i, j, 0) + zp.wt_b * du;
+        if (iny) DV_avg2(i, j, 0) = DV_avg2(i, j, 0) + zp.wt_b * dv;
+    }
 }
 __global__ void __launch_bounds__(RT_BX * U_BY)
 k2d_fused(K2Args a0)
@@ -380,6 +429,14 @@ k2d_fused(K2Args a0)
     constexpr int TR = (F_N + NT - 1) / NT;                  // tile points per thread
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
     const RhTile rh_t_ = rh_tile();
+    if (rh_t_.y >= a0.ntile_y) {
+        // ---- (0) the rows of the grid above the tiles: time averages on the ghost frame (k2d_frame's work, same expressions), one
+        // thread per frame point.  Frame points lie outside tbxp1, the tiles' owners inside: no two threads of the launch write the
+        // same element, and nothing written by this launch is read here.
+        const K2Args &L = k2_args_again();
+        k2_frame_point(L, ((rh_t_.y - L.ntile_y) * (int)gridDim.x + rh_t_.x) * NT + tid);
+        return;
+    }
     const int I0 = un.lo0 - 1 + rh_t_.x * U_SX, J0 = un.lo1 - 1 + rh_t_.y * U_SY;
     const int i = I0 + tx, j = J0 + ty;
     const bool in_rb = inb2(rb, i, j), in_un = inb2(un, i, j);
@@ -875,10 +932,9 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
         const dim3 grid((un.hi[0] - un.lo[0] + U_SX) / U_SX, (un.hi[1] - un.lo[1] + U_SY) / U_SY, 1);
         if (fused) {
             // tiles reach 2 points beyond the block's first / one beyond its last point: inside tbxp3 wherever they are consumed
+            // the ghost frame's time averages ride on extra rows of the same launch (one thread per frame point)
             const int nfr = (int)(bx_npts(tbxp3) - bx_npts(tbxp1));
-            k2d_frame<<<(nfr + 255) / 256, 256, 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkB(tbxp1), zp, mkA(zeta_rhs), mkA(s->h), mkA(ub_rhs), mkA(vb_rhs),
-                mkA(s->pm), mkA(s->pn), mkA(s->Zt_avg1), mkA(s->DU_avg1), mkA(s->DU_avg2), mkA(s->DV_avg1), mkA(s->DV_avg2), mkA(c->DUon), mkA(c->DVom), fb_work ? 1 : 0);
-            RH_LAUNCH_CHECK();
+            const int per_row = (int)grid.x * RT_BX * U_BY, frame_rows = (nfr + per_row - 1) / per_row;
             K2Arrays KA; memset(&KA, 0, sizeof KA);
             auto shape = [](const rh_array4 &a) { S2 q; q.lo0 = a.lo[0]; q.lo1 = a.lo[1]; q.hi0 = a.hi[0]; q.hi1 = a.hi[1]; q.sy = (unsigned)(a.hi[0] - a.lo[0] + 1); return q; };
             auto comp = [](const rh_array4 &a, int n) { return mkA(a, n).p; };
@@ -897,8 +953,8 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
             KA.pm = s->pm.p; KA.pn = s->pn.p; KA.msku = s->msku.p; KA.mskv = s->mskv.p; KA.mskp = s->mskp.p;
             if (s->pm.lo[2] != 0 || s->pn.lo[2] != 0 || s->msku.lo[2] != 0 || s->mskv.lo[2] != 0 || s->mskp.lo[2] != 0) return rh_fail("rh_advance_2d: 2-D arrays must sit on the k = 0 slab");
             const B2v vbx{b2.lo[0], b2.lo[1], b2.hi[0], b2.hi[1]};
-            K2Args ka; ka.vb = vbx; ka.P = P; ka.zp = zp; ka.A = KA; ka.ghost_from_mem = fb_work ? 1 : 0;
-            { TScope tk(c, "k2d_fused"); k2d_fused<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ka); }
+            K2Args ka; ka.vb = vbx; ka.P = P; ka.zp = zp; ka.A = KA; ka.ghost_from_mem = fb_work ? 1 : 0; ka.ntile_y = (int)grid.y;
+            { TScope tk(c, "k2d_fused"); k2d_fused<<<dim3(grid.x, grid.y + (unsigned)frame_rows, 1), dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ka); }
             RH_LAUNCH_CHECK();
         } else
         k2d_uvbar<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), mkB(tbxp1), P, mkA(ub_rhs), mkA(vb_rhs),

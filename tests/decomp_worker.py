@@ -43,8 +43,15 @@ def main():
     rx, ry = rank % px, rank // px
     jlo, jhi = slab_rows(ny, py, ry)
     ilo, ihi = slab_rows(nx, px, rx)
-    rem = REMORA(cfg, device="cuda:0", box=((ilo, jlo, 0), (ihi, jhi, nz - 1)), nranks=(px, py), rank_xy=(rx, ry))
-    rem.comm_set_host_transport(dist)
+    # REMORA_DECOMP_TRANSPORT=rccl: the library's built-in RCCL send/recv, one GPU per rank (LOCAL_RANK); the process group stays
+    # gloo (it only carries the 128-byte communicator id and the gathers of this script).  Default: all ranks on cuda:0, host-staged.
+    rccl = os.environ.get("REMORA_DECOMP_TRANSPORT", "") == "rccl"
+    dev = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}" if rccl and os.environ.get("REMORA_DECOMP_SHARE_GPU", "") != "1" else "cuda:0"
+    rem = REMORA(cfg, device=dev, box=((ilo, jlo, 0), (ihi, jhi, nz - 1)), nranks=(px, py), rank_xy=(rx, ry))
+    if rccl:
+        rem.comm_init(dist)
+    else:
+        rem.comm_set_host_transport(dist)
     ncalls = int(sys.argv[4]) if len(sys.argv) > 4 else -1          # debugging aid: stop after ncalls barotropic sub-steps of step 1
 
     def run(r):
@@ -75,7 +82,7 @@ def main():
     dist.gather_object(bytes(pb) if pb is not None else None, pbs if rank == 0 else None, dst=0)
     ok = True
     if rank == 0:
-        ref = REMORA(cfg, device="cuda:0")
+        ref = REMORA(cfg, device=dev)
         run(ref)
         for f in fields:
             g, glo, ghi = ref.get(f)

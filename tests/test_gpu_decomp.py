@@ -21,3 +21,25 @@ def test_decomposed_equals_single_box(case, world, port, grid):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     out = r.stdout + r.stderr
     assert r.returncode == 0 and "DECOMP_OK" in out, out[-4000:]
+
+
+def _ngpu():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("async_rccl", ["0", "1"])
+@pytest.mark.parametrize("case,world,port,grid", [("Seamount", 2, 29631, "1x2"), ("Upwelling", 2, 29632, "2x1"), ("DoubleGyre", 2, 29633, "1x2"),
+                                                  ("Seamount", 4, 29634, "2x2"), ("DoubleGyre", 4, 29635, "2x2")])
+def test_decomposed_equals_single_box_over_rccl(case, world, port, grid, async_rccl):
+    """The same check over the library's built-in RCCL transport (ncclSend / ncclRecv, rh_comm.hip), one GPU per rank, with the
+    side-stream fills off and on (RH_ASYNC_RCCL).  Needs as many GPUs as ranks: skipped on a one-GPU box."""
+    if _ngpu() < world:
+        pytest.skip(f"{world} GPUs needed, {_ngpu()} visible")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", REMORA_DECOMP_TRANSPORT="rccl",
+               RH_ASYNC_RCCL=async_rccl)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port + (10 if async_rccl == "1" else 0)), os.path.join(ROOT, "tests", "decomp_worker.py"), case, "3", grid]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "DECOMP_OK" in out, out[-4000:]

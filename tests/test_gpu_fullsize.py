@@ -29,8 +29,11 @@ def _case(nx, ny, nz):
     return c
 
 
-def test_full_size_x_invariance_and_embedding():
-    nx, ny, nz, steps = 2048, 2048, 50, 2
+@pytest.mark.parametrize("nx,ny,nz", [(2048, 2048, 50), (4096, 2048, 64)])
+def test_full_size_x_invariance_and_embedding(nx, ny, nz):
+    """(2048, 2048, 50): the single-GPU roofline size (BASELINE.json configs[3]).  (4096, 2048, 64): one rank's block of configs[4]
+    (8192 x 8192 x 64 over a 2 x 4 process grid), Upwelling physics as configs[4] names it: 5.4e8 cells, ~170 GB of state."""
+    steps = 2
     big = REMORA(_case(nx, ny, nz), device="cuda:0")
     big.InitData()
     big.Evolve(steps)
