@@ -169,6 +169,7 @@ struct rh_ctx {
     bool nofuse2d = false;           // RH_NOFUSE2D=1: advance_2d as three kernels + the DUon/DVom exchange instead of k2d_fused (A/B parity)
     bool unfused = false;            // RH_UNFUSED=1: drivers call the per-leaf entry points instead of the fused kernels (A/B parity)
     bool gls_libm_pow = false;       // RH_GLS_LIBM_POW=1: every per-point power of the GLS closure through pow() (A/B parity and timing)
+    bool no_bc2d = false;            // RH_NO_BC2D=1: the ghost cells of the barotropic step always through the batched BC passes, never in k2d_fused (A/B parity and timing)
     bool poison = false;             // RH_POISON=1: NaN-fill the work space at the start of every step (stale-read detector)
     ~rh_ctx() { if (bcq) bc_queue_delete(bcq); if (haloq) halo_queue_delete(haloq); }
 };

@@ -13,7 +13,7 @@ int rh_fail(const char *fmt, ...)
     return 1;
 }
 extern "C" const char *rh_last_error(void) { return g_rh_err.c_str(); }
-#define RH_BUILD_ID "r2_v4"
+#define RH_BUILD_ID "r2_v5"
 extern "C" const char *rh_build_id(void) { return RH_BUILD_ID; }
 
 // ------------------------------------------------------------------------------------------------ timing
@@ -313,6 +313,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     c->gls_libm_pow = getenv("RH_GLS_LIBM_POW") && atoi(getenv("RH_GLS_LIBM_POW")) != 0;
     c->no_async = getenv("RH_NO_ASYNC") && atoi(getenv("RH_NO_ASYNC")) != 0;
     c->async_rccl = getenv("RH_ASYNC_RCCL") && atoi(getenv("RH_ASYNC_RCCL")) != 0;
+    c->no_bc2d = getenv("RH_NO_BC2D") && atoi(getenv("RH_NO_BC2D")) != 0;
     c->poison = getenv("RH_POISON") && atoi(getenv("RH_POISON")) != 0;
 
     // stretching curves (here N = nz, DepthStretchTransform.H:49)

@@ -346,7 +346,8 @@ struct B2v { int lo0, lo1, hi0, hi1; };      // the rank's valid cell box; every
 // output pointers, shapes, the time-stepping weights -- was parked in vector lanes across the whole kernel.  The kernel therefore
 // takes ONE struct and the later phases read their scalars again from the kernel-argument segment (scalar loads, served by the
 // scalar cache) through a pointer the compiler cannot trace back to the argument, so nothing has to stay live from phase to phase.
-struct K2Args { B2v vb; UVPar P; ZetaPar zp; K2Arrays A; int ghost_from_mem; int ntile_y; };    // ntile_y: rows of the grid that are tiles; the rows above carry the ghost frame
+struct K2Args { B2v vb; UVPar P; ZetaPar zp; K2Arrays A; int ghost_from_mem; int ntile_x, ntile_y, nframe;
+                double bc_ext[4]; int wallbc; };   // wallbc: all four sides are walls of a one-rank domain: the blocks on the rim also write the ghost cells of the new level (bc_ext: ubar x-lo / x-hi, vbar y-lo / y-hi ext_dir values)    // the launch's first nframe blocks (in tile order) carry the ghost frame, the next ntile_x * ntile_y are tiles
 __device__ __forceinline__ const K2Args &k2_args_again()
 {
     typedef const K2Args __attribute__((address_space(4))) *KP;
@@ -429,18 +430,18 @@ k2d_fused(K2Args a0)
     constexpr int TR = (F_N + NT - 1) / NT;                  // tile points per thread
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
     const RhTile rh_t_ = rh_tile();
-    if (rh_t_.y >= a0.ntile_y) {
-        // ---- (0) the rows of the grid above the tiles: time averages on the ghost frame (k2d_frame's work, same expressions), one
-        // thread per frame point.  Frame points lie outside tbxp1, the tiles' owners inside: no two threads of the launch write the
-        // same element, and nothing written by this launch is read here.
-        const K2Args &L = k2_args_again();
-        k2_frame_point(L, ((rh_t_.y - L.ntile_y) * (int)gridDim.x + rh_t_.x) * NT + tid);
-        return;
-    }
-    const int I0 = un.lo0 - 1 + rh_t_.x * U_SX, J0 = un.lo1 - 1 + rh_t_.y * U_SY;
+    // The first blocks of the launch (in the XCD-aware tile order) accumulate the time averages on the ghost frame -- k2d_frame's work,
+    // same expressions, one thread per frame point -- so that they run under the tiles instead of as a tail after them.  Frame points
+    // lie outside tbxp1, the tiles' owners inside: no two threads of the launch write the same element, and nothing written by this
+    // launch is read by the frame blocks.
+    const int lin = rh_t_.y * (int)gridDim.x + rh_t_.x - a0.nframe;
+    if (lin < 0) { const K2Args &L = k2_args_again(); k2_frame_point(L, (lin + L.nframe) * NT + tid); return; }
+    const int tile_x = lin % a0.ntile_x, tile_y = lin / a0.ntile_x;
+    if (tile_y >= a0.ntile_y) return;
+    const int I0 = un.lo0 - 1 + tile_x * U_SX, J0 = un.lo1 - 1 + tile_y * U_SY;
     const int i = I0 + tx, j = J0 + ty;
     const bool in_rb = inb2(rb, i, j), in_un = inb2(un, i, j);
-    const bool owner = in_rb && (tx >= 1 || rh_t_.x == 0) && (ty >= 1 || rh_t_.y == 0);
+    const bool owner = in_rb && (tx >= 1 || tile_x == 0) && (ty >= 1 || tile_y == 0);
     const bool is_u = tx >= 1 && ty <= U_BY - 2 && inb2(xb, i, j), is_v = tx <= RT_BX - 2 && ty >= 1 && inb2(yb, i, j);
 
     // ---- (1) all global loads.  Tile points first: t = tid, tid + NT, ...
@@ -569,7 +570,17 @@ k2d_fused(K2Args a0)
             zw0 = cff5 * zn0 + cff4 * zr0;
         }
         if (owner) {
-            zeta_new(i, j, 0) = zn0;                                           // :450-454
+            if (!L.wallbc) zeta_new(i, j, 0) = zn0;                            // :450-454
+            else if (i >= P.dlox && i <= P.dhix && j >= P.dloy && j <= P.dhiy) {
+                // walls: the ghost cells of zeta(knew) end as copies of the nearest valid cell -- what FillPatch's foextrap passes
+                // (sides, then the rows over the full width, then 0.5 * (x + x) in the corners; REMORA_BoundaryConditions_cons.cpp:
+                // 170-337) leave there -- so the cell next to a wall writes them and the ring of tbxp1 is not stored at all
+                zeta_new(i, j, 0) = zn0;
+                const int ci = (i == P.dlox) ? -1 : ((i == P.dhix) ? 1 : 0), cj = (j == P.dloy) ? -1 : ((j == P.dhiy) ? 1 : 0);
+                if (ci) for (int g = 1; g <= 3; g++) zeta_new(i + ci * g, j, 0) = zn0;
+                if (cj) for (int g = 1; g <= 3; g++) zeta_new(i, j + cj * g, 0) = zn0;
+                if (ci && cj) for (int gj = 1; gj <= 3; gj++) for (int gi = 1; gi <= 3; gi++) zeta_new(i + ci * gi, j + cj * gj, 0) = zn0;
+            }
             if (zp.predictor) rzeta_rhs(i, j, 0) = div;                        // :459-464
         }
     }
@@ -656,9 +667,37 @@ k2d_fused(K2Args a0)
         const double cff = (pm0 + pmx) * (pn0 + pnx);
         const double Dnew_avg = 1.0 / ((zn0 + h0) + (w[Q_ZN * NT] + hx));
         const double mu = u_msk;
-        if (!P.am3) ub_new(i, j, 0) = (u_stp * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mu;
-        else ub_new(i, j, 0) = (u_stp * (Dstp0 + Dstp1) +
-                                cff * (P.c1 * rhs + P.c2 * u_rs - P.c3 * u_rp)) * Dnew_avg * mu;
+        double ubv;
+        if (!P.am3) ubv = (u_stp * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mu;
+        else ubv = (u_stp * (Dstp0 + Dstp1) +
+                    cff * (P.c1 * rhs + P.c2 * u_rs - P.c3 * u_rp)) * Dnew_avg * mu;
+        if (L.wallbc) {
+            // REMORA_BoundaryConditions_xvel.cpp:56-265 for walls on all sides, as its passes leave ubar(knew): ext_dir on the wall
+            // face and the two ghost faces behind it; foextrap (x msku) into the two ghost rows; 0.5 * (side + row) in the corners
+            const V2 msku{L.A.smu, L.A.msku};
+            auto MU = [&](int ii, int jj) -> double { return P.nomask ? 1.0 : msku(ii, jj, 0); };
+            const bool xlo = (i == P.dlox), xhi = (i == P.dhix + 1);
+            if (xlo || xhi) {
+                const double ext = xlo ? L.bc_ext[0] : L.bc_ext[1]; const int sgn = xlo ? -1 : 1;
+                ubv = ext * MU(i, j);
+                ub_new(i + sgn, j, 0) = ext * MU(i + sgn, j); ub_new(i + 2 * sgn, j, 0) = ext * MU(i + 2 * sgn, j);
+            } else if (j == P.dloy || j == P.dhiy) {
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                    if (side == 0 ? (j != P.dloy) : (j != P.dhiy)) continue;
+                    const int sgn = side == 0 ? -1 : 1;
+                    for (int g = 1; g <= 2; g++) ub_new(i, j + sgn * g, 0) = ubv * MU(i, j + sgn * g);
+                    // the corner blocks hang on the first / last interior face of the row
+                    if (i == P.dlox + 1)
+                        for (int g = 1; g <= 2; g++) for (int ic = P.dlox - 2; ic <= P.dlox; ic++)
+                            ub_new(ic, j + sgn * g, 0) = 0.5 * (L.bc_ext[0] * MU(ic, j) + ubv * MU(i, j + sgn * g));
+                    if (i == P.dhix)
+                        for (int g = 1; g <= 2; g++) for (int ic = P.dhix + 1; ic <= P.dhix + 3; ic++)
+                            ub_new(ic, j + sgn * g, 0) = 0.5 * (L.bc_ext[1] * MU(ic, j) + ubv * MU(i, j + sgn * g));
+                }
+            }
+        }
+        ub_new(i, j, 0) = ubv;
         if (P.predictor) rubar_rhs(i, j, 0) = rhs;
     }
     if (is_v) {
@@ -702,9 +741,34 @@ k2d_fused(K2Args a0)
         const double cff = (pm0 + pmy) * (pn0 + pny);
         const double Dnew_avg = 1.0 / ((zn0 + h0) + (sp[Q_ZN * NT] + hy));
         const double mv = v_msk;
-        if (!P.am3) vb_new(i, j, 0) = (v_stp * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mv;
-        else vb_new(i, j, 0) = (v_stp * (Dstp0 + Dstp1) +
-                                cff * (P.c1 * rhs + P.c2 * v_rs - P.c3 * v_rp)) * Dnew_avg * mv;
+        double vbv;
+        if (!P.am3) vbv = (v_stp * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mv;
+        else vbv = (v_stp * (Dstp0 + Dstp1) +
+                    cff * (P.c1 * rhs + P.c2 * v_rs - P.c3 * v_rp)) * Dnew_avg * mv;
+        if (L.wallbc) {                                      // REMORA_BoundaryConditions_yvel.cpp:55-265, the mirror image
+            const V2 mskv{L.A.smv, L.A.mskv};
+            auto MV = [&](int ii, int jj) -> double { return P.nomask ? 1.0 : mskv(ii, jj, 0); };
+            const bool ylo = (j == P.dloy), yhi = (j == P.dhiy + 1);
+            if (ylo || yhi) {
+                const double ext = ylo ? L.bc_ext[2] : L.bc_ext[3]; const int sgn = ylo ? -1 : 1;
+                vbv = ext * MV(i, j);
+                vb_new(i, j + sgn, 0) = ext * MV(i, j + sgn); vb_new(i, j + 2 * sgn, 0) = ext * MV(i, j + 2 * sgn);
+            } else if (i == P.dlox || i == P.dhix) {
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                    if (side == 0 ? (i != P.dlox) : (i != P.dhix)) continue;
+                    const int sgn = side == 0 ? -1 : 1;
+                    for (int g = 1; g <= 2; g++) vb_new(i + sgn * g, j, 0) = vbv * MV(i + sgn * g, j);
+                    if (j == P.dloy + 1)
+                        for (int g = 1; g <= 2; g++) for (int jc = P.dloy - 2; jc <= P.dloy; jc++)
+                            vb_new(i + sgn * g, jc, 0) = 0.5 * (vbv * MV(i + sgn * g, j) + L.bc_ext[2] * MV(i, jc));
+                    if (j == P.dhiy)
+                        for (int g = 1; g <= 2; g++) for (int jc = P.dhiy + 1; jc <= P.dhiy + 3; jc++)
+                            vb_new(i + sgn * g, jc, 0) = 0.5 * (vbv * MV(i + sgn * g, j) + L.bc_ext[3] * MV(i, jc));
+                }
+            }
+        }
+        vb_new(i, j, 0) = vbv;
         if (P.predictor) rvbar_rhs(i, j, 0) = rhs;
     }
     }
@@ -866,6 +930,16 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
                            same2({&s->ubar, &s->rubar, &s->rufrc, &s->ru2d, &s->DU_avg1, &s->DU_avg2, &c->DUon}) &&
                            same2({&s->vbar, &s->rvbar, &s->rvfrc, &s->rv2d, &s->DV_avg1, &s->DV_avg2, &c->DVom});
     const bool fused = !c->unfused && !c->nofuse2d && my_iif < nfast && shapes_ok;   // the last call only accumulates the averages (:362-363): three-kernel form
+    // Walls on all four sides of a one-rank domain (e.g. Exec/DoubleGyre): FillPatch of the new level is local to the rim, and the
+    // fused kernel's rim blocks do it (three to four launches fewer per call).  Everything else takes the batched BC passes.
+    auto wall = [&](int v, int dn, int dt_) {              // variable v: ext_dir in its normal direction dn, foextrap in the other
+        return c->bcs[v].lo[dn] == RH_BC_EXT_DIR && c->bcs[v].hi[dn] == RH_BC_EXT_DIR && c->bcs[v].lo[dt_] == RH_BC_FOEXTRAP && c->bcs[v].hi[dt_] == RH_BC_FOEXTRAP; };
+    const bool wallbc = fused && !c->no_bc2d && !c->prm.periodic[0] && !c->prm.periodic[1] && c->prm.nranks[0] <= 1 && c->prm.nranks[1] <= 1 &&
+        b2.hi[0] - b2.lo[0] >= 2 && b2.hi[1] - b2.lo[1] >= 2 && wall(RH_BCV_UBAR, 0, 1) && wall(RH_BCV_VBAR, 1, 0) &&
+        c->bcs[RH_BCV_ZETA].lo[0] == RH_BC_FOEXTRAP && c->bcs[RH_BCV_ZETA].hi[0] == RH_BC_FOEXTRAP && c->bcs[RH_BCV_ZETA].lo[1] == RH_BC_FOEXTRAP && c->bcs[RH_BCV_ZETA].hi[1] == RH_BC_FOEXTRAP &&
+        s->zeta.lo[0] == b2.lo[0] - 3 && s->zeta.hi[0] == b2.hi[0] + 3 && s->zeta.lo[1] == b2.lo[1] - 3 && s->zeta.hi[1] == b2.hi[1] + 3 &&
+        s->ubar.lo[0] == b2.lo[0] - 2 && s->ubar.hi[0] == b2.hi[0] + 3 && s->ubar.lo[1] == b2.lo[1] - 2 && s->ubar.hi[1] == b2.hi[1] + 2 &&
+        s->vbar.lo[0] == b2.lo[0] - 2 && s->vbar.hi[0] == b2.hi[0] + 2 && s->vbar.lo[1] == b2.lo[1] - 2 && s->vbar.hi[1] == b2.hi[1] + 3;
     // ---- Drhs, DUon, DVom (:149-166) and their ghost exchange (:170-171)
     RH_NEED(s->zeta, tbxp3); RH_NEED(s->h, tbxp3);
     RH_NEED(s->ubar, xgbx2); RH_NEED(s->vbar, ygbx2); RH_NEED(c->DUon, xgbx2); RH_NEED(c->DVom, ygbx2);
@@ -934,7 +1008,7 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
             // tiles reach 2 points beyond the block's first / one beyond its last point: inside tbxp3 wherever they are consumed
             // the ghost frame's time averages ride on extra rows of the same launch (one thread per frame point)
             const int nfr = (int)(bx_npts(tbxp3) - bx_npts(tbxp1));
-            const int per_row = (int)grid.x * RT_BX * U_BY, frame_rows = (nfr + per_row - 1) / per_row;
+            const int nfb = (nfr + RT_BX * U_BY - 1) / (RT_BX * U_BY), frame_rows = (nfb + (int)grid.x - 1) / (int)grid.x;
             K2Arrays KA; memset(&KA, 0, sizeof KA);
             auto shape = [](const rh_array4 &a) { S2 q; q.lo0 = a.lo[0]; q.lo1 = a.lo[1]; q.hi0 = a.hi[0]; q.hi1 = a.hi[1]; q.sy = (unsigned)(a.hi[0] - a.lo[0] + 1); return q; };
             auto comp = [](const rh_array4 &a, int n) { return mkA(a, n).p; };
@@ -953,7 +1027,9 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
             KA.pm = s->pm.p; KA.pn = s->pn.p; KA.msku = s->msku.p; KA.mskv = s->mskv.p; KA.mskp = s->mskp.p;
             if (s->pm.lo[2] != 0 || s->pn.lo[2] != 0 || s->msku.lo[2] != 0 || s->mskv.lo[2] != 0 || s->mskp.lo[2] != 0) return rh_fail("rh_advance_2d: 2-D arrays must sit on the k = 0 slab");
             const B2v vbx{b2.lo[0], b2.lo[1], b2.hi[0], b2.hi[1]};
-            K2Args ka; ka.vb = vbx; ka.P = P; ka.zp = zp; ka.A = KA; ka.ghost_from_mem = fb_work ? 1 : 0; ka.ntile_y = (int)grid.y;
+            K2Args ka; ka.vb = vbx; ka.P = P; ka.zp = zp; ka.A = KA; ka.ghost_from_mem = fb_work ? 1 : 0; ka.ntile_x = (int)grid.x; ka.ntile_y = (int)grid.y; ka.nframe = nfb;
+            ka.wallbc = wallbc ? 1 : 0;
+            ka.bc_ext[0] = c->extdir[RH_BCV_UBAR][0]; ka.bc_ext[1] = c->extdir[RH_BCV_UBAR][3]; ka.bc_ext[2] = c->extdir[RH_BCV_VBAR][1]; ka.bc_ext[3] = c->extdir[RH_BCV_VBAR][4];
             { TScope tk(c, "k2d_fused"); k2d_fused<<<dim3(grid.x, grid.y + (unsigned)frame_rows, 1), dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ka); }
             RH_LAUNCH_CHECK();
         } else
@@ -967,6 +1043,7 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
         RH_LAUNCH_CHECK();
     }
     // ---- ghost cells of the new time level, :735-755
+    if (wallbc) return 0;                                  // the rim blocks of k2d_fused wrote them
     BcScope bcs(c);
     RH_TRY(halo_fillpatch(c, mfv(c, s->ubar, 1, 0, 0), s->msku, RH_BCV_UBAR, knew, 1));
     RH_TRY(halo_fillpatch(c, mfv(c, s->vbar, 0, 1, 0), s->mskv, RH_BCV_VBAR, knew, 1));
