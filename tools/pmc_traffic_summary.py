@@ -29,7 +29,13 @@ n_copy = 2 * ((nx + g) * (ny + g) * nz * 3 + (nx + 1 + g) * (ny + g) * nz + (nx 
 known = n_copy * 8.0
 assert fc["k_copy"] == 8 and wc["k_copy"] == 8, (fc["k_copy"], wc["k_copy"])
 cal_r = known / fs["k_copy"]; cal_w = known / ws["k_copy"]
-res = {"calibration": {"kernel": "k_copy x8", "known_bytes_each_way": known, "bytes_per_FETCH_SIZE_unit": cal_r, "bytes_per_WRITE_SIZE_unit": cal_w},
+builds = set()
+for c in ("FETCH_SIZE", "WRITE_SIZE"):      # the library build both passes ran (bench.py prints it in its JSON line)
+    for line in open(f"gpurun_out/pmc_{tag}_{c}/bench.json"):
+        if line.startswith("{"):
+            builds.add(json.loads(line).get("build"))
+assert len(builds) == 1, builds
+res = {"build": builds.pop(), "calibration": {"kernel": "k_copy x8", "known_bytes_each_way": known, "bytes_per_FETCH_SIZE_unit": cal_r, "bytes_per_WRITE_SIZE_unit": cal_w},
        "cells": nx * ny * nz, "kernels": {}}
 cells = nx * ny * nz
 print(f"calibration: 1 FETCH_SIZE unit = {cal_r:.1f} B, 1 WRITE_SIZE unit = {cal_w:.1f} B")
