@@ -28,8 +28,12 @@ extern "C" {
 typedef struct { double *p; int lo[3]; int hi[3]; int ncomp; } rh_array4;
 typedef struct { int lo[3]; int hi[3]; } rh_box;
 
-/* mathematical boundary types, Source/REMORA_IndexDefines.H:61-73 (only these three are implemented on device) */
-enum { RH_BC_INT_DIR = 0, RH_BC_FOEXTRAP = 2, RH_BC_EXT_DIR = 3 };
+/* mathematical boundary types, Source/REMORA_IndexDefines.H:61-73 */
+enum { RH_BC_REFLECT_ODD = -1, RH_BC_INT_DIR = 0, RH_BC_REFLECT_EVEN = 1, RH_BC_FOEXTRAP = 2, RH_BC_EXT_DIR = 3, RH_BC_CLAMPED = 4,
+       RH_BC_CHAPMAN = 5, RH_BC_FLATHER = 6, RH_BC_ORLANSKI_RAD = 7, RH_BC_ORLANSKI_RAD_NUDGE = 8 };
+/* physical boundary kinds: enum struct REMORA_BC, Source/REMORA_IndexDefines.H:53-56 (the words of bc.<side|var>.type) */
+enum { RH_PBC_SYMMETRY = 0, RH_PBC_INFLOW, RH_PBC_OUTFLOW, RH_PBC_NO_SLIP_WALL, RH_PBC_SLIP_WALL, RH_PBC_PERIODIC, RH_PBC_CLAMPED,
+       RH_PBC_CHAPMAN, RH_PBC_FLATHER, RH_PBC_ORLANSKI_RAD, RH_PBC_ORLANSKI_RAD_NUDGE, RH_PBC_UNDEFINED };
 /* BCVars, Source/REMORA_IndexDefines.H:15-34 */
 enum { RH_BCV_CONS = 0, RH_BCV_XVEL = 3, RH_BCV_YVEL, RH_BCV_ZVEL, RH_BCV_UBAR, RH_BCV_VBAR, RH_BCV_ZETA, RH_BCV_TKE,
        RH_BCV_FOEXTRAP_PERIODIC, RH_BCV_FOEXTRAP, RH_BCV_U2D_SIMPLE, RH_BCV_V2D_SIMPLE, RH_BCV_NUM };
@@ -89,11 +93,26 @@ const char *rh_last_error(void);
 const char *rh_build_id(void);
 
 /* ---- context ------------------------------------------------------------------------------------- */
-/* Builds the context: BC table (REMORA::init_bcs, Initialization/REMORA_init_bcs.cpp:9-679, SlipWall/periodic subset),
+/* Builds the context: BC table (REMORA::init_bcs, Initialization/REMORA_init_bcs.cpp:9-679; every non-periodic side starts as
+ * SlipWall, rh_set_bc changes that),
  * barotropic filter weights (REMORA::set_weights, TimeIntegration/REMORA_set_weights.cpp:10-171), stretching curves
  * (k-only part of Utils/REMORA_DepthStretchTransform.H:81-139) and device work space.  stream: hipStream_t or NULL. */
 int  rh_create(const rh_params *prm, void *stream, rh_ctx **out);
 int  rh_destroy(rh_ctx *ctx);
+/* REMORA::init_bcs for one variable and face: what "bc.<var>.type" (remora.boundary_per_variable = 1) or "bc.<side>.type" puts
+ * into phys_bc_type (Initialization/REMORA_init_bcs.cpp:9-199), followed by the translation into the per-component mathematical
+ * types (:201-679), which is redone as a whole on every call.  bcvar: one of the ten user variables in BCVars order (RH_BCV_CONS+0
+ * temp, +1 salt, +2 scalar, RH_BCV_XVEL u, RH_BCV_YVEL v, RH_BCV_ZVEL w, RH_BCV_UBAR, RH_BCV_VBAR, RH_BCV_ZETA, RH_BCV_TKE), or
+ * -1 for all ten (the bc.<side>.type form).  face: amrex::Orientation index 0 xlo, 1 ylo, 3 xhi, 4 yhi (z faces are always
+ * SlipWall, :130).  kind: RH_PBC_*.  value: bc.<>.velocity[component] / bc.<>.scalar of an inflow face (velocity of a no-slip
+ * face: its normal component is forced to 0, :51), ignored otherwise.  Errors where the reference aborts: a non-periodic kind on a
+ * periodic direction and vice versa, chapman on anything but zeta, flather on anything but ubar / vbar, kinds a variable's
+ * translation does not accept (:307,:407,:539,:624).  clamped / chapman / flather / orlanski_rad_nudg sides are filled as the
+ * reference's physbc fills them; the boundary DATA those kinds relax to comes from fill_from_bdyfiles (NetCDF), which is outside
+ * this library. */
+int  rh_set_bc(rh_ctx *ctx, int bcvar, int face, int kind, double value);
+/* the translated table: out6 = lo(x,y,z), hi(x,y,z) mathematical types of BCVars entry bccomp (domain_bcs_type[bccomp]) */
+int  rh_get_bc(const rh_ctx *ctx, int bccomp, int out6[6]);
 int  rh_nfast(const rh_ctx *ctx);                                  /* REMORA::nfast (REMORA.H:937) */
 int  rh_weights(const rh_ctx *ctx, double *w1, double *w2);        /* vec_weight1/2, 2*ndtfast+1 values each (host) */
 int  rh_sync(rh_ctx *ctx);                                         /* hipStreamSynchronize on the context's stream */
@@ -143,10 +162,19 @@ int  rh_halo_plan_i(const rh_params *prm, const int arr_lo[3], const int arr_hi[
 /* amrex::FabArray::FillBoundary(periodicity) for comps [icomp,icomp+ncomp): periodic wrap and, across ranks,
  * neighbour exchange (call sites: SURVEY.md section 2.4).  valid = a's box shrunk by ng. */
 int  rh_fill_boundary(rh_ctx *ctx, rh_array4 a, const int ng[3], int icomp, int ncomp);
-/* REMORAPhysBCFunct::operator() (BoundaryConditions/REMORA_PhysBCFunct.cpp:21-93) for int_dir/foextrap/ext_dir sides */
+/* REMORAPhysBCFunct::operator() (BoundaryConditions/REMORA_PhysBCFunct.cpp:21-93; impose_cons_bcs / impose_xvel_bcs /
+ * impose_yvel_bcs / impose_zvel_bcs, BoundaryConditions/REMORA_BoundaryConditions_{cons,xvel,yvel,zvel}.cpp) with an empty mf_calc:
+ * an orlanski_rad side is an error here (the reference reads an empty Array4 there) */
 int  rh_physbc(rh_ctx *ctx, rh_array4 a, const int ng[3], rh_array4 msk, int icomp, int ncomp, int bccomp);
 /* REMORA::FillPatch at level 0 (BoundaryConditions/REMORA_FillPatch.cpp:16-155) = rh_fill_boundary + rh_physbc */
 int  rh_fill_patch(rh_ctx *ctx, rh_array4 a, const int ng[3], rh_array4 msk, int bccomp, int icomp, int ncomp);
+/* The same with the arguments the radiation condition reads (PhysBCFunct.cpp:21-23): n_not_fill, mf_calc (the previous time level;
+ * calc.p = NULL stands for the empty MultiFab; calc may be the filled array itself, as in REMORA::InitData, REMORA.cpp:293-295: the
+ * passes then run in the order of the reference's CPU loops) and, for cell-centred arrays, msku / mskv. */
+int  rh_physbc_calc(rh_ctx *ctx, rh_array4 a, const int ng[3], rh_array4 msk, int icomp, int ncomp, int bccomp, int n_not_fill,
+                    rh_array4 calc, rh_array4 msku, rh_array4 mskv);
+int  rh_fill_patch_calc(rh_ctx *ctx, rh_array4 a, const int ng[3], rh_array4 msk, int bccomp, int icomp, int ncomp,
+                        rh_array4 calc, rh_array4 msku, rh_array4 mskv);
 
 /* ---- leaves (Box/Array4 level, Source/REMORA.H:454-648) -------------------------------------------- */
 /* REMORA::stretch_transform, Utils/REMORA_DepthStretchTransform.H:12-249 (z_w, z_r, Hz, h comp 1 from h, Zt_avg1) */

@@ -398,9 +398,9 @@ OState* o_create(const Params *prm)
     }
     init_smflux(s,0.0);
     /* REMORA::InitData, Source/REMORA.cpp:293-304 */
-    o_fillpatch(&s->geom,&s->cons_new,F(mskr),BCV_CONS,0,NCONS);
-    o_fillpatch(&s->geom,&s->xvel_new,F(msku),BCV_XVEL,0,1);
-    o_fillpatch(&s->geom,&s->yvel_new,F(mskv),BCV_YVEL,0,1);
+    o_fillpatch_calc(&s->geom,&s->cons_new,F(mskr),BCV_CONS,0,NCONS,F(cons_new),F(msku),F(mskv));   /* mf_calc = the array itself */
+    o_fillpatch_calc(&s->geom,&s->xvel_new,F(msku),BCV_XVEL,0,1,F(xvel_new),F(msku),F(mskv));
+    o_fillpatch_calc(&s->geom,&s->yvel_new,F(mskv),BCV_YVEL,0,1,F(yvel_new),F(msku),F(mskv));
     o_fillpatch(&s->geom,&s->zvel_new,F(mskr),BCV_ZVEL,0,1);
     memcpy(F(cons_old).p,F(cons_new).p,sizeof(double)*fab_size(F(cons_new)));
     memcpy(F(xvel_old).p,F(xvel_new).p,sizeof(double)*fab_size(F(xvel_new)));
@@ -528,7 +528,7 @@ void o_setup_step(OState *s)
             o_fillpatch(g,&s->gls,F(mskr),BCV_ZVEL,ic,1);
         }
     }
-    o_fillpatch(g,&s->sstore,F(mskr),BCV_CONS,0,NCONS);                         /* :363 */
+    o_fillpatch_calc(g,&s->sstore,F(mskr),BCV_CONS,0,NCONS,F(cons_old),F(msku),F(mskv));   /* :363, mf_calc = cons_old */
     o_fill_boundary(g,&s->Huon,0,1);                                           /* :367-368 */
     o_fill_boundary(g,&s->Hvom,0,1);
     mf_free(&mf_W); mf_free(&mf_DC); mf_free(&mf_rho);
@@ -801,8 +801,9 @@ static void advance_3d(OState *s)
         o_vert_mean_3d(ybx,0,1,v,Hz,F(DV_avg1),mf_DC.f,CF,pm,F(mskv),nnew,N);
         fab_free(&FC); fab_free(&BC); fab_free(&CF);
     }
-    o_physbc(g,&s->xvel_new,F(msku),0,1,BCV_XVEL,0);                           /* :154-155 */
-    o_physbc(g,&s->yvel_new,F(mskv),0,1,BCV_YVEL,0);
+    { Fab none; memset(&none,0,sizeof none);                                   /* :154-155, mf_calc = xvel_old / yvel_old */
+      o_physbc_calc(g,&s->xvel_new,F(msku),0,1,BCV_XVEL,0,F(xvel_old),none,none);
+      o_physbc_calc(g,&s->yvel_new,F(mskv),0,1,BCV_YVEL,0,F(yvel_old),none,none); }
     {
         Fab FC=fab_alloc(gbx2,1);                                              /* :194-218 */
         fab_setval_box(FC,gbx2,0.0); fab_setval_box(mf_DC.f,box_grow(gbx2,0,0,1),0.0);
@@ -833,7 +834,7 @@ static void advance_3d(OState *s)
                        F(msku),F(mskv),nrhs,nnew,N,dt_lev);
         fab_free(&FC);
     }
-    o_fillpatch(g,&s->cons_new,F(mskr),BCV_CONS,0,NCONS);                       /* :350 */
+    o_fillpatch_calc(g,&s->cons_new,F(mskr),BCV_CONS,0,NCONS,F(cons_old),F(msku),F(mskv));   /* :350, mf_calc = cons_old */
     {
         Box tbxp2=box_grow(bx,NGROW,NGROW,0), tbxp21=box_grow(bx,NGROW,NGROW,NGROW-1);
         /* reference allocates FC,BC on tbxp2 (cell) although vert_visc indexes k=N+1 on DC only; give them the k-face box */
@@ -853,7 +854,7 @@ void o_advance_3d_ml(OState *s)
     o_fill_boundary(g,&s->yvel_new,0,1);
     advance_3d(s);
     for(int n=0;n<3;n++){ o_fill_boundary(g,&s->ubar,n,1); o_fill_boundary(g,&s->vbar,n,1); }   /* :33-38 */
-    o_fillpatch(g,&s->cons_new,F(mskr),BCV_CONS,0,NCONS);                       /* :45 */
+    o_fillpatch_calc(g,&s->cons_new,F(mskr),BCV_CONS,0,NCONS,F(cons_old),F(msku),F(mskv));   /* :45, mf_calc = cons_old */
     o_fill_boundary(g,&s->xvel_new,0,1);
     o_fill_boundary(g,&s->yvel_new,0,1);
     o_fillpatch(g,&s->zvel_new,F(mskr),BCV_ZVEL,0,1);                           /* :48 */

@@ -17,7 +17,12 @@
 #define NGROW 2
 
 /* mathematical BC types, Source/REMORA_IndexDefines.H:61-73 */
-enum { BC_BOGUS=-666, BC_REFLECT_ODD=-1, BC_INT_DIR=0, BC_REFLECT_EVEN=1, BC_FOEXTRAP=2, BC_EXT_DIR=3 };
+enum { BC_BOGUS=-666, BC_REFLECT_ODD=-1, BC_INT_DIR=0, BC_REFLECT_EVEN=1, BC_FOEXTRAP=2, BC_EXT_DIR=3,
+       BC_CLAMPED=4, BC_CHAPMAN=5, BC_FLATHER=6, BC_ORLANSKI_RAD=7, BC_ORLANSKI_RAD_NUDGE=8 };
+/* physical boundary kinds, enum struct REMORA_BC, Source/REMORA_IndexDefines.H:53-56 */
+enum { PBC_SYMMETRY=0, PBC_INFLOW, PBC_OUTFLOW, PBC_NO_SLIP_WALL, PBC_SLIP_WALL, PBC_PERIODIC, PBC_CLAMPED, PBC_CHAPMAN,
+       PBC_FLATHER, PBC_ORLANSKI_RAD, PBC_ORLANSKI_RAD_NUDGE, PBC_UNDEFINED };
+#define BCV_USER 10   /* temp, salt, scalar, u, v, w, ubar, vbar, zeta, tke: the variables of remora.boundary_per_variable */
 /* BCVars, Source/REMORA_IndexDefines.H:15-34 */
 enum { BCV_CONS=0, BCV_TEMP=0, BCV_SALT, BCV_SCALAR, BCV_XVEL=NCONS, BCV_YVEL, BCV_ZVEL, BCV_UBAR, BCV_VBAR,
        BCV_ZETA, BCV_TKE, BCV_FOEXTRAP_PERIODIC, BCV_FOEXTRAP, BCV_U2D_SIMPLE, BCV_V2D_SIMPLE, BCV_NUM };
@@ -51,6 +56,12 @@ typedef struct {
     double z0, zRef, uRef;       /* DoublyPeriodic prob.z0 / prob.zRef / prob.uRef (log-layer x-velocity) */
     GlsParams gls;
     int    threads;              /* OpenMP threads for the timing baseline (0/1 = serial) */
+    /* bc.<var>.type (remora.boundary_per_variable = 1) or bc.<side>.type: PBC_* per variable (BCVars order) and amrex orientation
+     * (0 xlo, 1 ylo, 3 xhi, 4 yhi; z is always SlipWall).  bc_set = 0: the table is ignored and every non-periodic side is
+     * SlipWall (the pinned cases).  bc_val: bc.<>.velocity[component] / bc.<>.scalar of an inflow or no-slip side. */
+    int    bc_set;
+    int    bc_kind[BCV_USER][6];
+    double bc_val[BCV_USER][6];
 } Params;
 
 typedef struct {
@@ -59,6 +70,7 @@ typedef struct {
     const Params *prm;
     BCRec bcs[BCV_NUM];
     double extdir[BCV_NUM][6];
+    int  phys[BCV_USER][6];      /* phys_bc_type */
 } Geom;
 
 /* ---- leaves (leaves.c) ---- */
@@ -100,6 +112,12 @@ void o_fill_boundary(const Geom*,MF *mf,int icomp,int ncomp);     /* single-box 
 void o_physbc(const Geom*,MF *mf,Fab msk,int icomp,int ncomp,int bccomp,int n_not_fill);
 /* REMORA::FillPatch at level 0 == FillBoundary + physbc (BoundaryConditions/REMORA_FillPatch.cpp:96-125) */
 void o_fillpatch(const Geom*,MF *mf,Fab msk,int bccomp,int icomp,int ncomp);
+/* the same with the arrays the radiation conditions read: mf_calc (a Fab with p = NULL stands for the reference's empty MultiFab)
+ * and, for cell-centred arrays, msku / mskv (REMORA_PhysBCFunct.cpp:21-23, REMORA_FillPatch.cpp:128-129) */
+void o_physbc_calc(const Geom*,MF *mf,Fab msk,int icomp,int ncomp,int bccomp,int n_not_fill,Fab calc,Fab msku,Fab mskv);
+void o_fillpatch_calc(const Geom*,MF *mf,Fab msk,int bccomp,int icomp,int ncomp,Fab calc,Fab msku,Fab mskv);
+/* mathematical types of one BCVars entry: out6 = lo(0..2), hi(0..2) */
+void o_get_bc(const Geom*,int bccomp,int *out6);
 
 /* ---- GLS closure (gls.c) ---- */
 void o_gls_prestep(const Geom*,Box vbx,Fab gls,Fab tke,Fab W,Fab Huon,Fab Hvom,Fab Hz,Fab pm,Fab pn,Fab msku,Fab mskv,

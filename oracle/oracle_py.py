@@ -27,7 +27,8 @@ class Params(C.Structure):
                 ("tcline", C.c_double), ("rdrag", C.c_double), ("coriolis_f0", C.c_double), ("coriolis_beta", C.c_double),
                 ("hmix_constant", C.c_int), ("visc2", C.c_double), ("tnu2", C.c_double * 3), ("prob", C.c_int),
                 ("u_0", C.c_double), ("v_0", C.c_double), ("z0", C.c_double), ("zRef", C.c_double), ("uRef", C.c_double),
-                ("gls", GlsParams), ("threads", C.c_int)]
+                ("gls", GlsParams), ("threads", C.c_int),
+                ("bc_set", C.c_int), ("bc_kind", (C.c_int * 6) * 10), ("bc_val", (C.c_double * 6) * 10)]
 
 
 def build(force=False):
@@ -89,6 +90,15 @@ def make_params(case, threads=1):
             p.gls.on = 1
             for gk, gv in v.items():
                 setattr(p.gls, gk, GLS_STAB[gv] if gk == "stab" else gv)
+        elif k == "bc":
+            from remora_amd.cases import PBC, BC_VARS
+            p.bc_set = 1
+            for iv, var in enumerate(BC_VARS):
+                for o in range(6):
+                    p.bc_kind[iv][o] = PBC[v[var].get(o, "slipwall")]
+                    p.bc_val[iv][o] = case.get("bc_val", {}).get(var, {}).get(o, 0.0)
+        elif k == "bc_val":
+            pass
         elif isinstance(v, (tuple, list)):
             arr = getattr(p, k)
             for i, x in enumerate(v):
@@ -192,7 +202,12 @@ BCV_NUM = 14
 
 class OGeom(C.Structure):
     _fields_ = [("domain", OBox), ("per", C.c_int * 2), ("prm", C.POINTER(Params)), ("bcs", OBCRec * BCV_NUM),
-                ("extdir", (C.c_double * 6) * BCV_NUM)]
+                ("extdir", (C.c_double * 6) * BCV_NUM), ("phys", (C.c_int * 6) * 10)]
+
+
+class OMF(C.Structure):
+    """oracle.h: MF -- one-box MultiFab: data on the grown box, valid box, index type, ghost widths"""
+    _fields_ = [("f", OFab), ("valid", OBox), ("ix", C.c_int * 3), ("ng", C.c_int * 3)]
 
 
 def obox(lo, hi):
@@ -228,13 +243,40 @@ def geom(case):
     g.per[0], g.per[1] = case["periodic"]
     g.prm = C.pointer(p)
     g._keep = p
+    lib().o_init_bcs.argtypes = [C.POINTER(OGeom)]
+    lib().o_init_bcs(C.byref(g))
     return g
+
+
+def omf(arr, lo, ix, ng):
+    """MF over a [comp, k, j, i] array whose first element sits at index lo: valid box = the array's box shrunk by ng"""
+    m = OMF()
+    m.f = ofab(arr, lo)
+    for d in range(3):
+        m.valid.lo[d] = m.f.lo[d] + ng[d]
+        m.valid.hi[d] = m.f.hi[d] - ng[d]
+        m.ix[d] = ix[d]
+        m.ng[d] = ng[d]
+    return m
+
+
+def null_fab():
+    return OFab()
+
+
+def get_bc(g, bccomp):
+    out = (C.c_int * 6)()
+    lib().o_get_bc.argtypes = [C.POINTER(OGeom), C.c_int, C.c_int * 6]
+    lib().o_get_bc(C.byref(g), bccomp, out)
+    return list(out)
 
 
 _G = C.POINTER(OGeom)
 _F = OFab
 _B = OBox
 LEAVES = {
+    "o_physbc_calc": [C.POINTER(OGeom), C.POINTER(OMF), OFab, C.c_int, C.c_int, C.c_int, C.c_int, OFab, OFab, OFab],
+    "o_fillpatch_calc": [C.POINTER(OGeom), C.POINTER(OMF), OFab, C.c_int, C.c_int, C.c_int, OFab, OFab, OFab],
     "o_omega": [_B] + [_F] * 5 + [C.c_int],
     "o_prestep_t_advection": [_G, _B, _B] + [_F] * 15 + [C.c_int] * 4 + [C.c_double],
     "o_prestep_diffusion": [_G, _B, _B, C.c_int, C.c_int] + [_F] * 12 + [C.c_int] * 6 + [C.c_double, C.c_double],

@@ -59,6 +59,41 @@ CASES["Channel_Test"] = dict(_DEFAULTS, prob="Channel_Test", ncell=(20, 60, 50),
                                       Akt_bak=1.0e-6, Zos=0.002, Zob=0.002))
 
 
+# physical boundary kinds: the words bc.<>.type accepts (Initialization/REMORA_init_bcs.cpp:12-101) in the order of enum struct
+# REMORA_BC (REMORA_IndexDefines.H:53-56)
+PBC = {"symmetry": 0, "inflow": 1, "outflow": 2, "noslipwall": 3, "slipwall": 4, "periodic": 5, "clamped": 6, "chapman": 7,
+       "flather": 8, "orlanski_rad": 9, "orlanski_rad_nudg": 10, "null": 11}
+BC_VARS = ("temp", "salt", "scalar", "u", "v", "w", "ubar", "vbar", "zeta", "tke")      # f_by_var order, init_bcs.cpp:185-194 = BCVars 0..9
+XLO, YLO, XHI, YHI = 0, 1, 3, 4                                                        # amrex::Orientation indices
+
+
+def bc_per_variable(**words):
+    """remora.boundary_per_variable = 1: bc.<var>.type = w0 w1 w2 w3.  The four words go to the faces xlo, yhi, xhi, ylo IN THAT
+    ORDER (init_bcs.cpp:144 builds the list that way; its comment says "west, south, east, north").  Variables left out are
+    "null" on every face (an abort in init_bcs unless the direction is periodic), except w, which defaults to outflow (:149-151)."""
+    out = {}
+    for v in BC_VARS:
+        w = words.get(v, ("outflow",) * 4 if v == "w" else ("null",) * 4)
+        assert len(w) == 4
+        out[v] = {XLO: w[0].lower(), YHI: w[1].lower(), XHI: w[2].lower(), YLO: w[3].lower()}
+    return out
+
+
+def bc_per_side(xlo=None, xhi=None, ylo=None, yhi=None):
+    """bc.<side>.type = word: every variable gets the side's kind (f_by_side, init_bcs.cpp:126-139)"""
+    return {v: {XLO: (xlo or "null").lower(), XHI: (xhi or "null").lower(), YLO: (ylo or "null").lower(), YHI: (yhi or "null").lower()}
+            for v in BC_VARS}
+
+
+# Exec/Channel_Test/inputs_orlanski: the channel with four open sides; tracers and 3-D momentum radiate (Orlanski), the
+# barotropic variables and tke are zero-gradient.  Not in the reference's CTest list: no gold file pins it.
+_orl = ("orlanski_rad",) * 4
+_out = ("outflow",) * 4
+CASES["Channel_Test_orlanski"] = dict(CASES["Channel_Test"], periodic=(0, 0),
+                                      bc=bc_per_variable(temp=_orl, salt=_orl, scalar=_orl, u=_orl, v=_orl, ubar=_out, vbar=_out,
+                                                         zeta=_out, tke=_out))
+
+
 def get(name):
     return copy.deepcopy(CASES[name])
 

@@ -138,6 +138,7 @@ struct rh_ctx {
     rh_box dom, bx;                  // domain and this rank's valid cell box
     int nfast; std::vector<double> w1, w2;
     BCRec3 bcs[RH_BCV_NUM]; double extdir[RH_BCV_NUM][6];
+    int phys[10][6]; double physval[10][6];      // phys_bc_type per user variable and face (init_bcs.cpp:9-199), inflow values
     // stretching curves (host-computed, device copy): [4][nz+1] = sc_w, Cs_w, sc_r, Cs_r
     std::vector<double> h_sc; double *d_sc = nullptr;
     // device work space (replaces the per-call MultiFab / FArrayBox temporaries of the reference)
@@ -185,8 +186,11 @@ struct TScope {
 MFV  mfv(const rh_ctx *c, const rh_array4 &a, int ix0, int ix1, int ix2);
 // halo / bc (rh_halo.hip)
 int  halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp);
-int  halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill);
-int  halo_fillpatch(rh_ctx *c, const MFV &m, const rh_array4 &msk, int bccomp, int icomp, int ncomp);
+// calc / msku / mskv: what the radiation conditions read (PhysBCFunct.cpp:21-23); null = the reference's empty MultiFab
+int  halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill,
+                 const rh_array4 *calc = nullptr, const rh_array4 *msku = nullptr, const rh_array4 *mskv = nullptr);
+int  halo_fillpatch(rh_ctx *c, const MFV &m, const rh_array4 &msk, int bccomp, int icomp, int ncomp,
+                    const rh_array4 *calc = nullptr, const rh_array4 *msku = nullptr, const rh_array4 *mskv = nullptr);
 int  halo_flush(rh_ctx *c);
 // fork: later ghost fills run on the side stream (after everything queued on the compute stream so far); end: back to the compute
 // stream, which does NOT wait; join: the compute stream waits for the side stream's fills (no-op when nothing is pending)

@@ -13,7 +13,7 @@ int rh_fail(const char *fmt, ...)
     return 1;
 }
 extern "C" const char *rh_last_error(void) { return g_rh_err.c_str(); }
-#define RH_BUILD_ID "r2_v5"
+#define RH_BUILD_ID "r2_v6"
 extern "C" const char *rh_build_id(void) { return RH_BUILD_ID; }
 
 // ------------------------------------------------------------------------------------------------ timing
@@ -172,28 +172,140 @@ static void stretch_coeffs(int k, int N, double theta_s, double theta_b, double 
     *sc_w_o = sc_w; *Cs_w_o = Cs_w; *sc_r_o = sc_r; *Cs_r_o = Cs_r;
 }
 
-// REMORA::init_bcs, Source/Initialization/REMORA_init_bcs.cpp:9-679, for the periodic / SlipWall sides the pinned cases use
-static void init_bcs(rh_ctx *c)
+// REMORA::init_bcs, Source/Initialization/REMORA_init_bcs.cpp:201-679: phys_bc_type -> domain_bcs_type (the mathematical type of every
+// BCVars component on every face) and m_bc_extdir_vals
+static int translate_bcs(rh_ctx *c)
 {
     const int BOGUS = -666;
-    auto setall = [&](int v, int dir, int t) { c->bcs[v].lo[dir] = t; c->bcs[v].hi[dir] = t; };
+    auto put = [&](int v, int dir, int hi, int t) { if (hi) c->bcs[v].hi[dir] = t; else c->bcs[v].lo[dir] = t; };
     for (int v = 0; v < RH_BCV_NUM; v++) for (int d = 0; d < 3; d++) { c->bcs[v].lo[d] = BOGUS; c->bcs[v].hi[d] = BOGUS; }
     for (int v = 0; v < RH_BCV_NUM; v++) for (int o = 0; o < 6; o++) c->extdir[v][o] = 0.0;
     for (int o = 0; o < 6; o++) { c->extdir[0][o] = 1.e19; c->extdir[1][o] = 1.e20; c->extdir[2][o] = 1.e21; }   // :161-163
-    for (int dir = 0; dir < 3; dir++) {
-        const int per = (dir < 2) ? c->prm.periodic[dir] : 0;      // z is always SlipWall (:130)
-        const int base = per ? RH_BC_INT_DIR : RH_BC_FOEXTRAP;
-        setall(RH_BCV_XVEL, dir, base); setall(RH_BCV_YVEL, dir, base);                      // :218-309
-        if (!per && dir < 2) setall(RH_BCV_XVEL + dir, dir, RH_BC_EXT_DIR);
-        setall(RH_BCV_ZVEL, dir, RH_BC_FOEXTRAP);                                            // :311-316
-        for (int n = 0; n < RH_NCONS; n++) setall(RH_BCV_CONS + n, dir, base);               // :331-409
-        setall(RH_BCV_UBAR, dir, base); setall(RH_BCV_VBAR, dir, base);                      // :425-541
-        setall(RH_BCV_U2D_SIMPLE, dir, base); setall(RH_BCV_V2D_SIMPLE, dir, base);
-        if (!per && dir < 2) { setall(RH_BCV_UBAR + dir, dir, RH_BC_EXT_DIR); setall(RH_BCV_U2D_SIMPLE + dir, dir, RH_BC_EXT_DIR); }
-        setall(RH_BCV_ZETA, dir, base); setall(RH_BCV_TKE, dir, base);                       // :556-627
-        setall(RH_BCV_FOEXTRAP_PERIODIC, dir, RH_BC_FOEXTRAP);                               // :636-648
-        setall(RH_BCV_FOEXTRAP, dir, RH_BC_FOEXTRAP);                                        // :655-667
+    for (int v = 0; v < 10; v++) for (int o = 0; o < 6; o++) {
+        const int dir = o % 3, kind = c->phys[v][o];
+        const bool vel = (v == RH_BCV_XVEL || v == RH_BCV_YVEL || v == RH_BCV_ZVEL);
+        if (kind == RH_PBC_INFLOW && (vel || v == RH_BCV_CONS + 2)) c->extdir[v][o] = c->physval[v][o];                       // :27-36
+        if (kind == RH_PBC_NO_SLIP_WALL && vel) c->extdir[v][o] = (v - RH_BCV_XVEL == dir) ? 0.0 : c->physval[v][o];           // :43-54
     }
+    for (int o = 0; o < 6; o++) {                                                                // :210-318 velocities
+        const int dir = o % 3, hi = o / 3;
+        for (int i = 0; i < 2; i++) {
+            const int v = RH_BCV_XVEL + i;
+            switch (c->phys[v][o]) {
+            case RH_PBC_SYMMETRY:     put(v, dir, hi, RH_BC_REFLECT_EVEN); if (i == 1) put(RH_BCV_XVEL + dir, dir, hi, RH_BC_REFLECT_ODD); break;
+            case RH_PBC_OUTFLOW:      put(v, dir, hi, RH_BC_FOEXTRAP); break;
+            case RH_PBC_INFLOW:
+            case RH_PBC_NO_SLIP_WALL: put(v, dir, hi, RH_BC_EXT_DIR); break;
+            case RH_PBC_SLIP_WALL:    put(v, dir, hi, RH_BC_FOEXTRAP); if (i == 1) put(RH_BCV_XVEL + dir, dir, hi, RH_BC_EXT_DIR); break;   // only the normal component is ext_dir
+            case RH_PBC_PERIODIC:     put(v, dir, hi, RH_BC_INT_DIR); break;
+            case RH_PBC_CLAMPED:      put(v, dir, hi, RH_BC_CLAMPED); break;
+            case RH_PBC_ORLANSKI_RAD: put(v, dir, hi, RH_BC_ORLANSKI_RAD); break;
+            case RH_PBC_ORLANSKI_RAD_NUDGE: put(v, dir, hi, RH_BC_ORLANSKI_RAD_NUDGE); break;
+            default: return rh_fail("init_bcs: Velocity boundary condition not validly specified (kind %d, face %d)", c->phys[v][o], o);
+            }
+        }
+        put(RH_BCV_ZVEL, dir, hi, RH_BC_FOEXTRAP);                                               // :311-316
+    }
+    for (int o = 0; o < 6; o++) {                                                                // :326-411 tracers
+        const int dir = o % 3, hi = o / 3;
+        for (int i = 0; i < RH_NCONS; i++) {
+            int t;
+            switch (c->phys[RH_BCV_CONS + i][o]) {
+            case RH_PBC_SYMMETRY: t = RH_BC_REFLECT_EVEN; break;
+            case RH_PBC_OUTFLOW: case RH_PBC_NO_SLIP_WALL: case RH_PBC_SLIP_WALL: t = RH_BC_FOEXTRAP; break;
+            case RH_PBC_INFLOW: t = RH_BC_EXT_DIR; break;
+            case RH_PBC_PERIODIC: t = RH_BC_INT_DIR; break;
+            case RH_PBC_CLAMPED: t = RH_BC_CLAMPED; break;
+            case RH_PBC_ORLANSKI_RAD: t = RH_BC_ORLANSKI_RAD; break;
+            case RH_PBC_ORLANSKI_RAD_NUDGE: t = RH_BC_ORLANSKI_RAD_NUDGE; break;
+            default: return rh_fail("init_bcs: Scalar/tracer boundary condition not validly specified (kind %d, face %d)", c->phys[RH_BCV_CONS + i][o], o);
+            }
+            put(RH_BCV_CONS + i, dir, hi, t);
+        }
+    }
+    for (int o = 0; o < 6; o++) {                                                                // :420-543 ubar, vbar and their simplified 2-D twins
+        const int dir = o % 3, hi = o / 3;
+        for (int i = 0; i < 2; i++) {
+            const int v = RH_BCV_UBAR + i, v2 = RH_BCV_U2D_SIMPLE + i;
+            const bool nrm = (i == 1 && dir != 2);
+            switch (c->phys[v][o]) {
+            case RH_PBC_SYMMETRY:
+                put(v, dir, hi, RH_BC_REFLECT_EVEN); put(v2, dir, hi, RH_BC_REFLECT_EVEN);
+                if (nrm) { put(RH_BCV_UBAR + dir, dir, hi, RH_BC_REFLECT_ODD); put(RH_BCV_U2D_SIMPLE + dir, dir, hi, RH_BC_REFLECT_ODD); }
+                break;
+            case RH_PBC_OUTFLOW:      put(v, dir, hi, RH_BC_FOEXTRAP); put(v2, dir, hi, RH_BC_FOEXTRAP); break;
+            case RH_PBC_INFLOW:
+            case RH_PBC_NO_SLIP_WALL: put(v, dir, hi, RH_BC_EXT_DIR); put(v2, dir, hi, RH_BC_EXT_DIR); break;
+            case RH_PBC_SLIP_WALL:
+                put(v, dir, hi, RH_BC_FOEXTRAP); put(v2, dir, hi, RH_BC_FOEXTRAP);
+                if (nrm) { put(RH_BCV_UBAR + dir, dir, hi, RH_BC_EXT_DIR); put(RH_BCV_U2D_SIMPLE + dir, dir, hi, RH_BC_EXT_DIR); }
+                break;
+            case RH_PBC_PERIODIC:     put(v, dir, hi, RH_BC_INT_DIR); put(v2, dir, hi, RH_BC_INT_DIR); break;
+            case RH_PBC_CLAMPED:      put(v, dir, hi, RH_BC_CLAMPED); put(v2, dir, hi, RH_BC_FOEXTRAP); break;
+            case RH_PBC_FLATHER:
+                put(v, dir, hi, RH_BC_CHAPMAN); put(v2, dir, hi, RH_BC_FOEXTRAP);
+                if (nrm) { put(RH_BCV_UBAR + dir, dir, hi, RH_BC_FLATHER); put(RH_BCV_U2D_SIMPLE + dir, dir, hi, RH_BC_FOEXTRAP); }
+                break;
+            default: return rh_fail("init_bcs: ubar or vbar boundary condition not validly specified (kind %d, face %d)", c->phys[v][o], o);
+            }
+        }
+    }
+    for (int o = 0; o < 6; o++) {                                                                // :551-628 zeta, tke
+        const int dir = o % 3, hi = o / 3;
+        for (int i = 0; i < 2; i++) {
+            int t;
+            switch (c->phys[RH_BCV_ZETA + i][o]) {
+            case RH_PBC_SYMMETRY: t = RH_BC_REFLECT_EVEN; break;
+            case RH_PBC_OUTFLOW: case RH_PBC_NO_SLIP_WALL: case RH_PBC_SLIP_WALL: t = RH_BC_FOEXTRAP; break;
+            case RH_PBC_INFLOW: t = RH_BC_EXT_DIR; break;
+            case RH_PBC_PERIODIC: t = RH_BC_INT_DIR; break;
+            case RH_PBC_CHAPMAN: t = RH_BC_CHAPMAN; break;
+            case RH_PBC_CLAMPED: t = RH_BC_CLAMPED; break;
+            default: return rh_fail("init_bcs: Free surface (zeta) boundary condition not validly specified (kind %d, face %d)", c->phys[RH_BCV_ZETA + i][o], o);
+            }
+            put(RH_BCV_ZETA + i, dir, hi, t);
+        }
+    }
+    for (int o = 0; o < 6; o++) {                                                                // :636-667
+        put(RH_BCV_FOEXTRAP_PERIODIC, o % 3, o / 3, RH_BC_FOEXTRAP);
+        put(RH_BCV_FOEXTRAP, o % 3, o / 3, RH_BC_FOEXTRAP);
+    }
+    return 0;
+}
+// the state REMORA::init_bcs reaches for the pinned inputs: periodic where the geometry is, SlipWall elsewhere (z: always, :130)
+static int init_bcs(rh_ctx *c)
+{
+    for (int v = 0; v < 10; v++) for (int o = 0; o < 6; o++) {
+        const int dir = o % 3;
+        c->phys[v][o] = (dir < 2 && c->prm.periodic[dir]) ? RH_PBC_PERIODIC : RH_PBC_SLIP_WALL;
+        c->physval[v][o] = 0.0;
+    }
+    return translate_bcs(c);
+}
+extern "C" int rh_set_bc(rh_ctx *c, int bcvar, int face, int kind, double value)
+{
+    if (!c) return rh_fail("rh_set_bc: null context");
+    if (!(face == 0 || face == 1 || face == 3 || face == 4)) return rh_fail("rh_set_bc: face %d is not one of 0 xlo, 1 ylo, 3 xhi, 4 yhi", face);
+    if (bcvar < -1 || bcvar >= 10) return rh_fail("rh_set_bc: variable %d is not one of the ten user variables", bcvar);
+    if (kind < 0 || kind >= RH_PBC_UNDEFINED) return rh_fail("rh_set_bc: This BC type is unknown (%d)", kind);                    // :117-121
+    const int dir = face % 3;
+    if (c->prm.periodic[dir] && kind != RH_PBC_PERIODIC) return rh_fail("rh_set_bc: Wrong BC type for periodic boundary");         // :107-115
+    if (!c->prm.periodic[dir] && kind == RH_PBC_PERIODIC) return rh_fail("rh_set_bc: Periodic boundary specified in a non-periodic direction");   // :96-98
+    int saved[10][6]; double savedv[10][6];
+    memcpy(saved, c->phys, sizeof saved); memcpy(savedv, c->physval, sizeof savedv);
+    for (int v = (bcvar < 0 ? 0 : bcvar); v <= (bcvar < 0 ? 9 : bcvar); v++) {
+        if (kind == RH_PBC_CHAPMAN && v != RH_BCV_ZETA) { memcpy(c->phys, saved, sizeof saved); memcpy(c->physval, savedv, sizeof savedv); return rh_fail("rh_set_bc: Chapman BC can only be applied to zeta"); }   // :71-73
+        if (kind == RH_PBC_FLATHER && !(v == RH_BCV_UBAR || v == RH_BCV_VBAR)) { memcpy(c->phys, saved, sizeof saved); memcpy(c->physval, savedv, sizeof savedv); return rh_fail("rh_set_bc: Flather BC can only be applied to ubar or vbar"); }   // :80-82
+        c->phys[v][face] = kind; c->physval[v][face] = value;
+    }
+    if (translate_bcs(c)) { memcpy(c->phys, saved, sizeof saved); memcpy(c->physval, savedv, sizeof savedv); (void)translate_bcs(c); return 1; }
+    return 0;
+}
+extern "C" int rh_get_bc(const rh_ctx *c, int bccomp, int out6[6])
+{
+    if (!c || bccomp < 0 || bccomp >= RH_BCV_NUM) return rh_fail("rh_get_bc: component %d", bccomp);
+    for (int d = 0; d < 3; d++) { out6[d] = c->bcs[bccomp].lo[d]; out6[3 + d] = c->bcs[bccomp].hi[d]; }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ native state layout
@@ -306,7 +418,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     for (int d = 0; d < 2; d++) if (prm->periodic[d] && (c->dom.hi[d] - c->dom.lo[d] + 1) < 4) return bad("periodic direction shorter than the ghost width");
     c->bcq = bc_queue_new(); c->haloq = halo_queue_new();
     c->nfast = set_weights(prm->ndtfast, c->w1, c->w2);
-    init_bcs(c);
+    if (init_bcs(c)) return bad(rh_last_error());
     c->unfused = getenv("RH_UNFUSED") && atoi(getenv("RH_UNFUSED")) != 0;
     c->noregsolve = getenv("RH_NOREGSOLVE") && atoi(getenv("RH_NOREGSOLVE")) != 0;
     c->nofuse2d = getenv("RH_NOFUSE2D") && atoi(getenv("RH_NOFUSE2D")) != 0;

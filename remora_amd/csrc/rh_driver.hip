@@ -156,7 +156,7 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     {
         TScope t(c, "halo");
         BcScope bcs(c);
-        RH_TRY(halo_fillpatch(c, mfv(c, s->sstore, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS));  // :363
+        RH_TRY(halo_fillpatch(c, mfv(c, s->sstore, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS, &s->cons_old, &s->msku, &s->mskv));  // :363
         RH_TRY(halo_fill_boundary(c, mfv(c, s->Huon, 1, 0, 0), 0, 1));                             // :367-368
         RH_TRY(halo_fill_boundary(c, mfv(c, s->Hvom, 0, 1, 0), 0, 1));
         RH_TRY(bcs.end());
@@ -185,8 +185,8 @@ static int advance_3d(rh_ctx *c, rh_state *s, int istep)
     {
         TScope t(c, "halo");
         BcScope bcs(c);
-        RH_TRY(halo_physbc(c, mfv(c, s->xvel_new, 1, 0, 0), s->msku, 0, 1, RH_BCV_XVEL, 0));       // :154-155
-        RH_TRY(halo_physbc(c, mfv(c, s->yvel_new, 0, 1, 0), s->mskv, 0, 1, RH_BCV_YVEL, 0));
+        RH_TRY(halo_physbc(c, mfv(c, s->xvel_new, 1, 0, 0), s->msku, 0, 1, RH_BCV_XVEL, 0, &s->xvel_old));       // :154-155
+        RH_TRY(halo_physbc(c, mfv(c, s->yvel_new, 0, 1, 0), s->mskv, 0, 1, RH_BCV_YVEL, 0, &s->yvel_old));
         RH_TRY(bcs.end());
     }
     RH_TRY(rh_update_massflux_3d(c, gbx2, 1, 0, s->xvel_new, s->ubar, s->Huon, s->Hz, s->pn, s->DU_avg1, s->DU_avg2, s->msku, N));   // :213
@@ -197,7 +197,7 @@ static int advance_3d(rh_ctx *c, rh_state *s, int istep)
     if (!c->unfused) RH_TRY(launch_rhs_t3(c, s));                                                  // :341-346, 3 tracers in one sweep
     else for (int n = 0; n < RH_NCONS; n++)
         RH_TRY(rh_rhs_t_3d(c, bx, a4_comp(s->cons_new, n), a4_comp(s->sstore, n), s->Huon, s->Hvom, s->Hz, s->pn, s->pm, c->W, s->msku, s->mskv, N, dt));
-    { TScope t(c, "halo"); RH_TRY(halo_fillpatch(c, mfv(c, s->cons_new, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS)); }   // :350
+    { TScope t(c, "halo"); RH_TRY(halo_fillpatch(c, mfv(c, s->cons_new, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS, &s->cons_old, &s->msku, &s->mskv)); }   // :350
     for (int n = 0; n < RH_NCONS; n++)                                                             // :382-385
         RH_TRY(rh_vert_visc_3d(c, bx, 0, 0, a4_comp(s->cons_new, n), s->Hz, a4_comp(s->Akt, n), N, dt));
     return 0;
@@ -221,7 +221,7 @@ extern "C" int rh_advance_3d_ml(rh_ctx *c, rh_state *s, int istep)
         BcScope bcs(c);
         RH_TRY(halo_fill_boundary(c, mfv(c, s->ubar, 1, 0, 0), 0, 3));                             // :33-38
         RH_TRY(halo_fill_boundary(c, mfv(c, s->vbar, 0, 1, 0), 0, 3));
-        RH_TRY(halo_fillpatch(c, mfv(c, s->cons_new, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS)); // :45
+        RH_TRY(halo_fillpatch(c, mfv(c, s->cons_new, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS, &s->cons_old, &s->msku, &s->mskv)); // :45
         RH_TRY(halo_fill_boundary(c, mfv(c, s->xvel_new, 1, 0, 0), 0, 1));                         // :46-47
         RH_TRY(halo_fill_boundary(c, mfv(c, s->yvel_new, 0, 1, 0), 0, 1));
         RH_TRY(halo_fillpatch(c, mfv(c, s->zvel_new, 0, 0, 1), s->mskr, RH_BCV_ZVEL, 0, 1));       // :48
@@ -478,9 +478,10 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
         RH_LAUNCH_CHECK();
     } else RH_TRY(set_smflux(c, s, 0.0));
     // REMORA::InitData, Source/REMORA.cpp:293-304
-    RH_TRY(halo_fillpatch(c, mfv(c, s->cons_new, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS));
-    RH_TRY(halo_fillpatch(c, mfv(c, s->xvel_new, 1, 0, 0), s->msku, RH_BCV_XVEL, 0, 1));
-    RH_TRY(halo_fillpatch(c, mfv(c, s->yvel_new, 0, 1, 0), s->mskv, RH_BCV_YVEL, 0, 1));
+    // REMORA.cpp:293-295: mf_calc is the array being filled
+    RH_TRY(halo_fillpatch(c, mfv(c, s->cons_new, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS, &s->cons_new, &s->msku, &s->mskv));
+    RH_TRY(halo_fillpatch(c, mfv(c, s->xvel_new, 1, 0, 0), s->msku, RH_BCV_XVEL, 0, 1, &s->xvel_new));
+    RH_TRY(halo_fillpatch(c, mfv(c, s->yvel_new, 0, 1, 0), s->mskv, RH_BCV_YVEL, 0, 1, &s->yvel_new));
     RH_TRY(halo_fillpatch(c, mfv(c, s->zvel_new, 0, 0, 1), s->mskr, RH_BCV_ZVEL, 0, 1));
     RH_TRY(dev_copy(c, s->cons_old, s->cons_new)); RH_TRY(dev_copy(c, s->xvel_old, s->xvel_new));
     RH_TRY(dev_copy(c, s->yvel_old, s->yvel_new)); RH_TRY(dev_copy(c, s->zvel_old, s->zvel_new));

@@ -319,17 +319,22 @@ int halo_fill_boundary(rh_ctx *c, const MFV &m, int icomp, int ncomp)
 // overwrites what another wrote.  Passes are queued with the level of their deepest hazard (RAW / WAW / WAR against queued
 // passes on the same component) and flushed as ONE launch per level, 16 passes per launch: the three FillPatch calls that end
 // every barotropic call become 3 launches instead of ~28.
-enum { BCP_CONST = 0, BCP_COPY_I = 1, BCP_COPY_J = 2, BCP_CORNER = 3 };
+enum { BCP_CONST = 0, BCP_COPY_I = 1, BCP_COPY_J = 2, BCP_CORNER = 3, BCP_FLIP_I = 4, BCP_FLIP_J = 5, BCP_ORL_I = 6, BCP_ORL_J = 7 };
 struct BcDesc {
     double *d; const double *msk;            // component base of the destination; mask (k = 0 slab) or null
     unsigned sy, sz, msy;                    // strides of destination and mask
     int lo0, lo1, lo2, mlo0, mlo1;           // array origins
     int r0, r1, r2, nx, ny, nk;              // region
     int mode, si, sj; double val;
+    // radiation passes only: the previous time level (component base), the tangential mask of the gradients (or null), and the
+    // three lines of the stencil along the normal: B = the line the wave leaves from, B2 = the next one inwards, G = the line of
+    // `calc` the outgoing value is blended with
+    const double *calc, *mt; unsigned csy, csz, mtsy; int clo0, clo1, clo2, mtlo0, mtlo1, B, B2, G;
 };
 #define BC_BATCH 16
 struct BcBatch { int n; BcDesc q[BC_BATCH]; };
-// dest(i,j,k) = val*msk | dest(si,j,k)*msk | dest(i,sj,k)*msk | 0.5*(dest(i,sj,k)+dest(si,j,k));  msk == null: no mask factor
+// dest(i,j,k) = val*msk | dest(si,j,k)*msk | dest(i,sj,k)*msk | 0.5*(dest(i,sj,k)+dest(si,j,k)) | +-dest(si-i,j,k)*msk | +-dest(i,sj-j,k)*msk
+// | Orlanski radiation along i or j;  msk == null: no mask factor
 __global__ void k_bc_pass(BcBatch b)
 {
     const BcDesc &q = b.q[blockIdx.y];
@@ -339,12 +344,36 @@ __global__ void k_bc_pass(BcBatch b)
         const int i = q.r0 + (int)(g % nx), j = q.r1 + (int)((g / nx) % ny), k = q.r2 + (int)(g / (nx * ny));
         const unsigned kz = (unsigned)(k - q.lo2) * q.sz;
         auto at = [&](int ii, int jj) -> double & { return q.d[(unsigned)(ii - q.lo0) + (unsigned)(jj - q.lo1) * q.sy + kz]; };
-        double x;
+        double x, den = 1.0;
         if (q.mode == BCP_CONST) x = q.val;
         else if (q.mode == BCP_COPY_I) x = at(q.si, j);
         else if (q.mode == BCP_COPY_J) x = at(i, q.sj);
-        else x = 0.5 * (at(i, q.sj) + at(q.si, j));
+        else if (q.mode == BCP_CORNER) x = 0.5 * (at(i, q.sj) + at(q.si, j));
+        else if (q.mode == BCP_FLIP_I) { x = at(q.si - i, j); if (q.val < 0.0) x = -x; }
+        else if (q.mode == BCP_FLIP_J) { x = at(i, q.sj - j); if (q.val < 0.0) x = -x; }
+        else {
+            // REMORA_BoundaryConditions_cons.cpp:75-87 and its eleven siblings (cons :92-104,:119-131,:136-148; xvel :69-81,:105-117,
+            // :148-159,:172-183; yvel :67-78,:91-102,:127-138,:163-175), which differ only in the lines they address
+            const unsigned ckz = (unsigned)(k - q.clo2) * q.csz;
+            auto ca = [&](int ii, int jj) -> double { return q.calc[(unsigned)(ii - q.clo0) + (unsigned)(jj - q.clo1) * q.csy + ckz]; };
+            const bool ni = (q.mode == BCP_ORL_I);
+            const double cB = ni ? ca(q.B, j) : ca(i, q.B);
+            double gA = ni ? cB - ca(q.B, j - 1) : cB - ca(i - 1, q.B);
+            double gB = ni ? ca(q.B, j + 1) - cB : ca(i + 1, q.B) - cB;
+            if (q.mt) { const double m = q.mt[(unsigned)(i - q.mtlo0) + (unsigned)(j - q.mtlo1) * q.mtsy]; gA = gA * m; gB = gB * m; }
+            const double dB = ni ? at(q.B, j) : at(i, q.B), dB2 = ni ? at(q.B2, j) : at(i, q.B2);
+            double dTdt = cB - dB;
+            const double dTdn = dB - dB2;
+            if (dTdt * dTdn < 0.0) dTdt = 0.0;
+            const double dTan = (dTdt * (gA + gB) > 0.0) ? gA : gB;
+            const double s2 = dTdn * dTdn + dTan * dTan;
+            const double cff = (s2 < 1.0e-20) ? 1.0e-20 : s2;
+            const double Cn = dTdt * dTdn;
+            x = cff * (ni ? ca(q.G, j) : ca(i, q.G)) + Cn * dB;
+            den = cff + Cn;
+        }
         if (q.msk) x = x * q.msk[(unsigned)(i - q.mlo0) + (unsigned)(j - q.mlo1) * q.msy];
+        if (q.mode >= BCP_ORL_I) x = x / den;
         at(i, j) = x;
     }
 }
@@ -387,7 +416,11 @@ static bool bc_pending_on(rh_ctx *c, const double *p, long n)
     return false;
 }
 
-static int bc_pass(rh_ctx *c, const rh_array4 &dest, int comp, rh_box r, int mode, int si, int sj, double val, const rh_array4 *msk)
+// what a radiation pass reads besides the destination
+struct OrlArgs { const rh_array4 *calc; int ccomp; const rh_array4 *mt; int B, B2, G; };
+
+static int bc_pass(rh_ctx *c, const rh_array4 &dest, int comp, rh_box r, int mode, int si, int sj, double val, const rh_array4 *msk,
+                   const OrlArgs *orl = nullptr)
 {
     r = bx_and(r, bx_of(dest));
     if (!bx_ok(r)) return 0;
@@ -396,6 +429,8 @@ static int bc_pass(rh_ctx *c, const rh_array4 &dest, int comp, rh_box r, int mod
     // every source index must lie inside the array
     if ((mode == BCP_COPY_I || mode == BCP_CORNER) && (si < dest.lo[0] || si > dest.hi[0])) return rh_fail("bc_pass: source i outside array");
     if ((mode == BCP_COPY_J || mode == BCP_CORNER) && (sj < dest.lo[1] || sj > dest.hi[1])) return rh_fail("bc_pass: source j outside array");
+    if (mode == BCP_FLIP_I && (si - r.hi[0] < dest.lo[0] || si - r.lo[0] > dest.hi[0])) return rh_fail("bc_pass: mirrored i outside array");
+    if (mode == BCP_FLIP_J && (sj - r.hi[1] < dest.lo[1] || sj - r.lo[1] > dest.hi[1])) return rh_fail("bc_pass: mirrored j outside array");
     BcPending p; memset(&p, 0, sizeof p);
     p.q.d = d.p; p.q.sy = d.sy; p.q.sz = d.sz; p.q.lo0 = d.lo0; p.q.lo1 = d.lo1; p.q.lo2 = d.lo2;
     if (msk) {
@@ -410,6 +445,37 @@ static int bc_pass(rh_ctx *c, const rh_array4 &dest, int comp, rh_box r, int mod
     p.ra = none; p.rb = none;
     if (mode == BCP_COPY_I || mode == BCP_CORNER) { p.ra = r; p.ra.lo[0] = p.ra.hi[0] = si; }
     if (mode == BCP_COPY_J || mode == BCP_CORNER) { p.rb = r; p.rb.lo[1] = p.rb.hi[1] = sj; }
+    if (mode == BCP_FLIP_I) { p.ra = r; p.ra.lo[0] = si - r.hi[0]; p.ra.hi[0] = si - r.lo[0]; }
+    if (mode == BCP_FLIP_J) { p.ra = r; p.ra.lo[1] = sj - r.hi[1]; p.ra.hi[1] = sj - r.lo[1]; }
+    if (mode == BCP_ORL_I || mode == BCP_ORL_J) {
+        if (!orl || !orl->calc || !orl->calc->p)
+            return rh_fail("physbc: an orlanski_rad side needs the calc array (the reference reads an empty Array4 here; use rh_physbc_calc / rh_fill_patch_calc)");
+        if (!msk) return rh_fail("bc_pass: radiation pass without a mask");
+        const int nd = (mode == BCP_ORL_I) ? 0 : 1, td = 1 - nd;
+        const rh_array4 &ca = *orl->calc;
+        if (orl->ccomp < 0 || orl->ccomp >= ca.ncomp) return rh_fail("bc_pass: calc component");
+        if (a4_size(ca) >= (1L << 32)) return rh_fail("bc_pass: calc array too large for 32-bit indexing");
+        // the stencil: lines B, B2 of the destination; lines B (one more point either way along the side) and G of calc
+        rh_box sd = r; sd.lo[nd] = std::min(orl->B, orl->B2); sd.hi[nd] = std::max(orl->B, orl->B2);
+        if (!bx_contains(bx_of(dest), sd)) return rh_fail("bc_pass: radiation stencil outside the array");
+        rh_box sc = r; sc.lo[nd] = std::min(orl->B, orl->G); sc.hi[nd] = std::max(orl->B, orl->G); sc.lo[td] -= 1; sc.hi[td] += 1;
+        if (!bx_contains(bx_of(ca), sc)) return rh_fail("bc_pass: radiation stencil outside the calc array");
+        A4 cv = mkA(ca, orl->ccomp);
+        p.q.calc = cv.p; p.q.csy = cv.sy; p.q.csz = cv.sz; p.q.clo0 = cv.lo0; p.q.clo1 = cv.lo1; p.q.clo2 = cv.lo2;
+        if (orl->mt) {
+            if (!bx_contains(bx_of(*orl->mt), bx_slab(r, 2, 0))) return rh_fail("bc_pass: tangential mask does not cover the region");
+            p.q.mt = orl->mt->p; p.q.mtsy = (unsigned)(orl->mt->hi[0] - orl->mt->lo[0] + 1); p.q.mtlo0 = orl->mt->lo[0]; p.q.mtlo1 = orl->mt->lo[1];
+        }
+        p.q.B = orl->B; p.q.B2 = orl->B2; p.q.G = orl->G;
+        p.ra = sd;
+        if (cv.p == d.p) {
+            // calc is the destination itself (REMORA::InitData): its reads are hazards like any other.  A pass must not read what it
+            // writes except cell by cell: the caller splits the side so that the G line is a pass of its own
+            p.rb = sc;
+            rh_box gl = r; gl.lo[nd] = gl.hi[nd] = orl->G;
+            if (bx_ok(bx_and(r, gl)) && (r.lo[nd] != r.hi[nd])) return rh_fail("bc_pass: in-place radiation pass covers its own G line");
+        } else if (bc_pending_on(c, ca.p, a4_size(ca))) RH_TRY(bc_flush(c));
+    }
     std::vector<BcPending> &Q = *(std::vector<BcPending> *)c->bcq;
     p.level = 0;
     for (const BcPending &o : Q) {
@@ -420,6 +486,21 @@ static int bc_pass(rh_ctx *c, const rh_array4 &dest, int comp, rh_box r, int mod
     if (c->bc_defer <= 0) return bc_flush(c);
     return 0;
 }
+// one side of a radiation condition over region r (all its ghost lines).  With calc == dest the lines are issued in the order the
+// reference's CPU loops visit them (ascending index): below the domain the far lines read the old G line before it is
+// overwritten, above the domain the G line comes first and the far lines read its new value.
+static int bc_orlanski(rh_ctx *c, const rh_array4 &dest, int comp, rh_box r, int nd, int hi, const rh_array4 *msk, const OrlArgs &o)
+{
+    const int mode = nd == 0 ? BCP_ORL_I : BCP_ORL_J;
+    const bool inplace = o.calc && o.calc->p && mkA(*o.calc, o.ccomp).p == mkA(dest, comp).p;
+    rh_box rr = bx_and(r, bx_of(dest));
+    if (!inplace || !bx_ok(rr) || rr.lo[nd] == rr.hi[nd]) return bc_pass(c, dest, comp, r, mode, 0, 0, 0.0, msk, &o);
+    rh_box gl = rr; gl.lo[nd] = gl.hi[nd] = o.G;
+    rh_box far = rr; if (hi) far.lo[nd] = o.G + 1; else far.hi[nd] = o.G - 1;
+    if (!bx_ok(bx_and(rr, gl))) return bc_pass(c, dest, comp, r, mode, 0, 0, 0.0, msk, &o);      // G is not a ghost line of this side (velocity faces)
+    if (hi) { RH_TRY(bc_pass(c, dest, comp, gl, mode, 0, 0, 0.0, msk, &o)); return bc_pass(c, dest, comp, far, mode, 0, 0, 0.0, msk, &o); }
+    RH_TRY(bc_pass(c, dest, comp, far, mode, 0, 0, 0.0, msk, &o)); return bc_pass(c, dest, comp, gl, mode, 0, 0, 0.0, msk, &o);
+}
 
 // amrex::setBC: domain type where the box reaches the domain side, int_dir otherwise
 static BCRec3 setbc(const BCRec3 &d, const rh_box &bx, const rh_box &dom)
@@ -428,132 +509,181 @@ static BCRec3 setbc(const BCRec3 &d, const rh_box &bx, const rh_box &dom)
     for (int k = 0; k < 3; k++) { r.lo[k] = bx.lo[k] <= dom.lo[k] ? d.lo[k] : RH_BC_INT_DIR; r.hi[k] = bx.hi[k] >= dom.hi[k] ? d.hi[k] : RH_BC_INT_DIR; }
     return r;
 }
+// nodal-in-z arrays: init_bcs gives zvel_bc foextrap on every face (:311-316); anything else cannot reach impose_zvel
 static int supported(const BCRec3 &bc)
 {
     for (int d = 0; d < 3; d++) for (int t : {bc.lo[d], bc.hi[d]})
-        if (t != RH_BC_INT_DIR && t != RH_BC_FOEXTRAP && t != RH_BC_EXT_DIR && t != -666) return rh_fail("physbc: BC type %d is not implemented on device", t);
+        if (t != RH_BC_INT_DIR && t != RH_BC_FOEXTRAP && t != RH_BC_EXT_DIR && t != -666) return rh_fail("physbc: BC type %d on a w-point array", t);
     return 0;
 }
 
+// what REMORAPhysBCFunct::operator() takes besides the array and its mask (PhysBCFunct.cpp:21-23); null = the empty MultiFab
+struct BcAux { const rh_array4 *calc, *msku, *mskv; };
+static inline bool copy_like_cons(int t) { return t == RH_BC_FOEXTRAP || t == RH_BC_CLAMPED || t == RH_BC_CHAPMAN || t == RH_BC_ORLANSKI_RAD || t == RH_BC_ORLANSKI_RAD_NUDGE; }
+static inline bool skip_corner(int t) { return t == RH_BC_CLAMPED || t == RH_BC_FLATHER || t == RH_BC_CHAPMAN || t == RH_BC_ORLANSKI_RAD_NUDGE; }
+
 // REMORA_BoundaryConditions_cons.cpp:20-340
-static int impose_cons(rh_ctx *c, const MFV &m, const rh_array4 &mskr, int icomp, int ncomp, int bccomp, int nnf)
+static int impose_cons(rh_ctx *c, const MFV &m, const rh_array4 &mskr, int icomp, int ncomp, int bccomp, int nnf, const BcAux &aux)
 {
     const rh_box dom = c->dom, bx = bx_of(m.a), vb = m.valid;
     const int perx = c->prm.periodic[0], pery = c->prm.periodic[1];
+    const int dlx = dom.lo[0], dhx = dom.hi[0], dly = dom.lo[1], dhy = dom.hi[1];
     for (int n = 0; n < ncomp; n++) {
         const BCRec3 bc = setbc(c->bcs[bccomp + n], bx, dom);                                    // :33-34
-        RH_TRY(supported(bc));
         const double *ext = c->extdir[bccomp + n];
         const int cc = icomp + n;
         if (!perx) {                                                                             // :65-107
-            rh_box lo = bx; lo.hi[0] = dom.lo[0] - 1;
-            lo.lo[1] = std::max(vb.lo[1] - 1, dom.lo[1]); lo.hi[1] = std::min(vb.hi[1] + 1, dom.hi[1]);
-            rh_box hi = bx; hi.lo[0] = dom.hi[0] + 1; hi.lo[1] = lo.lo[1]; hi.hi[1] = lo.hi[1];
+            rh_box lo = bx; lo.hi[0] = dlx - 1;
+            lo.lo[1] = std::max(vb.lo[1] - 1, dly); lo.hi[1] = std::min(vb.hi[1] + 1, dhy);
+            rh_box hi = bx; hi.lo[0] = dhx + 1; hi.lo[1] = lo.lo[1]; hi.hi[1] = lo.hi[1];
             if (bc.lo[0] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, cc, lo, BCP_CONST, 0, 0, ext[0], &mskr));
+            else if (bc.lo[0] == RH_BC_ORLANSKI_RAD) { const OrlArgs o = {aux.calc, cc, aux.mskv, dlx, dlx + 1, dlx - 1}; RH_TRY(bc_orlanski(c, m.a, cc, lo, 0, 0, &mskr, o)); }
             if (bc.hi[0] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, cc, hi, BCP_CONST, 0, 0, ext[3], &mskr));
+            else if (bc.hi[0] == RH_BC_ORLANSKI_RAD) { const OrlArgs o = {aux.calc, cc, aux.mskv, dhx, dhx - 1, dhx + 1}; RH_TRY(bc_orlanski(c, m.a, cc, hi, 0, 1, &mskr, o)); }
         }
         if (!pery) {                                                                             // :109-151
-            rh_box lo = bx; lo.hi[1] = dom.lo[1] - 1;
-            lo.lo[0] = std::max(vb.lo[0] - 1, dom.lo[0]); lo.hi[0] = std::min(vb.hi[0] + 1, dom.hi[0]);
-            rh_box hi = bx; hi.lo[1] = dom.hi[1] + 1; hi.lo[0] = lo.lo[0]; hi.hi[0] = lo.hi[0];
+            rh_box lo = bx; lo.hi[1] = dly - 1;
+            lo.lo[0] = std::max(vb.lo[0] - 1, dlx); lo.hi[0] = std::min(vb.hi[0] + 1, dhx);
+            rh_box hi = bx; hi.lo[1] = dhy + 1; hi.lo[0] = lo.lo[0]; hi.hi[0] = lo.hi[0];
             if (bc.lo[1] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, cc, lo, BCP_CONST, 0, 0, ext[1], &mskr));
+            else if (bc.lo[1] == RH_BC_ORLANSKI_RAD) { const OrlArgs o = {aux.calc, cc, aux.msku, dly, dly + 1, dly - 1}; RH_TRY(bc_orlanski(c, m.a, cc, lo, 1, 0, &mskr, o)); }
             if (bc.hi[1] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, cc, hi, BCP_CONST, 0, 0, ext[4], &mskr));
+            else if (bc.hi[1] == RH_BC_ORLANSKI_RAD) { const OrlArgs o = {aux.calc, cc, aux.msku, dhy, dhy - 1, dhy + 1}; RH_TRY(bc_orlanski(c, m.a, cc, hi, 1, 1, &mskr, o)); }
         }
         // z sides (:153-168, :254-286): the arrays on this path carry no ghost cells in z, nothing to fill
         const int zl = std::max(dom.lo[2], bx.lo[2]), zh = std::min(dom.hi[2], bx.hi[2]);
         // 2-D arrays sit on the k = 0 slab whatever the domain's k range
         const int zlo = (bx.lo[2] == bx.hi[2]) ? bx.lo[2] : zl, zhi = (bx.lo[2] == bx.hi[2]) ? bx.hi[2] : zh;
-        rh_box xlo = bx; xlo.hi[0] = dom.lo[0] - 1 - nnf; xlo.lo[2] = zlo; xlo.hi[2] = zhi;      // :170-181
-        rh_box xhi = bx; xhi.lo[0] = dom.hi[0] + 1 + nnf; xhi.lo[2] = zlo; xhi.hi[2] = zhi;
-        rh_box ylo = bx; ylo.hi[1] = dom.lo[1] - 1 - nnf; ylo.lo[2] = zlo; ylo.hi[2] = zhi;
-        rh_box yhi = bx; yhi.lo[1] = dom.hi[1] + 1 + nnf; yhi.lo[2] = zlo; yhi.hi[2] = zhi;
+        rh_box xlo = bx; xlo.hi[0] = dlx - 1 - nnf; xlo.lo[2] = zlo; xlo.hi[2] = zhi;            // :170-181
+        rh_box xhi = bx; xhi.lo[0] = dhx + 1 + nnf; xhi.lo[2] = zlo; xhi.hi[2] = zhi;
+        rh_box ylo = bx; ylo.hi[1] = dly - 1 - nnf; ylo.lo[2] = zlo; ylo.hi[2] = zhi;
+        rh_box yhi = bx; yhi.lo[1] = dhy + 1 + nnf; yhi.lo[2] = zlo; yhi.hi[2] = zhi;
         if (!perx || bccomp == RH_BCV_FOEXTRAP) {                                                // :193-221
-            if (bc.lo[0] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, cc, xlo, BCP_COPY_I, dom.lo[0] - nnf, 0, 0.0, nullptr));
-            if (bc.hi[0] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, cc, xhi, BCP_COPY_I, dom.hi[0] + nnf, 0, 0.0, nullptr));
+            const int il = (bc.lo[0] == RH_BC_ORLANSKI_RAD) ? 1 : 0, ih = (bc.hi[0] == RH_BC_ORLANSKI_RAD) ? 1 : 0;
+            if (copy_like_cons(bc.lo[0])) RH_TRY(bc_pass(c, m.a, cc, xlo, BCP_COPY_I, dlx - nnf - il, 0, 0.0, nullptr));
+            else if (bc.lo[0] == RH_BC_REFLECT_EVEN || bc.lo[0] == RH_BC_REFLECT_ODD) RH_TRY(bc_pass(c, m.a, cc, xlo, BCP_FLIP_I, dlx - 1, 0, bc.lo[0] == RH_BC_REFLECT_ODD ? -1.0 : 1.0, nullptr));
+            if (copy_like_cons(bc.hi[0])) RH_TRY(bc_pass(c, m.a, cc, xhi, BCP_COPY_I, dhx + nnf + ih, 0, 0.0, nullptr));
+            else if (bc.hi[0] == RH_BC_REFLECT_EVEN || bc.hi[0] == RH_BC_REFLECT_ODD) RH_TRY(bc_pass(c, m.a, cc, xhi, BCP_FLIP_I, 2 * dhx + 1, 0, bc.hi[0] == RH_BC_REFLECT_ODD ? -1.0 : 1.0, nullptr));
         }
         if (!pery || bccomp == RH_BCV_FOEXTRAP) {                                                // :223-252
-            if (bc.lo[1] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, cc, ylo, BCP_COPY_J, 0, dom.lo[1] - nnf, 0.0, nullptr));
-            if (bc.hi[1] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, cc, yhi, BCP_COPY_J, 0, dom.hi[1] + nnf, 0.0, nullptr));
+            const int il = (bc.lo[1] == RH_BC_ORLANSKI_RAD) ? 1 : 0, ih = (bc.hi[1] == RH_BC_ORLANSKI_RAD) ? 1 : 0;
+            if (copy_like_cons(bc.lo[1])) RH_TRY(bc_pass(c, m.a, cc, ylo, BCP_COPY_J, 0, dly - nnf - il, 0.0, nullptr));
+            else if (bc.lo[1] == RH_BC_REFLECT_EVEN || bc.lo[1] == RH_BC_REFLECT_ODD) RH_TRY(bc_pass(c, m.a, cc, ylo, BCP_FLIP_J, 0, dly - 1, bc.lo[1] == RH_BC_REFLECT_ODD ? -1.0 : 1.0, nullptr));
+            // :242 asks the LOW side's type for orlanski_rad (sic)
+            if (bc.hi[1] == RH_BC_FOEXTRAP || bc.hi[1] == RH_BC_CLAMPED || bc.hi[1] == RH_BC_CHAPMAN || bc.lo[1] == RH_BC_ORLANSKI_RAD || bc.hi[1] == RH_BC_ORLANSKI_RAD_NUDGE)
+                RH_TRY(bc_pass(c, m.a, cc, yhi, BCP_COPY_J, 0, dhy + nnf + ih, 0.0, nullptr));
+            else if (bc.hi[1] == RH_BC_REFLECT_EVEN || bc.hi[1] == RH_BC_REFLECT_ODD) RH_TRY(bc_pass(c, m.a, cc, yhi, BCP_FLIP_J, 0, 2 * dhy + 1, bc.hi[1] == RH_BC_REFLECT_ODD ? -1.0 : 1.0, nullptr));
         }
         if ((!perx && !pery) || bccomp == RH_BCV_FOEXTRAP) {                                     // :287-337
-            RH_TRY(bc_pass(c, m.a, cc, bx_and(xlo, ylo), BCP_CORNER, dom.lo[0], dom.lo[1], 0.0, nullptr));
-            RH_TRY(bc_pass(c, m.a, cc, bx_and(xlo, yhi), BCP_CORNER, dom.lo[0], dom.hi[1], 0.0, nullptr));
-            RH_TRY(bc_pass(c, m.a, cc, bx_and(xhi, ylo), BCP_CORNER, dom.hi[0], dom.lo[1], 0.0, nullptr));
-            RH_TRY(bc_pass(c, m.a, cc, bx_and(xhi, yhi), BCP_CORNER, dom.hi[0], dom.hi[1], 0.0, nullptr));
+            if (!skip_corner(bc.lo[0]) && !skip_corner(bc.lo[1])) RH_TRY(bc_pass(c, m.a, cc, bx_and(xlo, ylo), BCP_CORNER, dlx, dly, 0.0, nullptr));
+            if (!skip_corner(bc.lo[0]) && !skip_corner(bc.hi[1])) RH_TRY(bc_pass(c, m.a, cc, bx_and(xlo, yhi), BCP_CORNER, dlx, dhy, 0.0, nullptr));
+            if (!skip_corner(bc.hi[0]) && !skip_corner(bc.lo[1])) RH_TRY(bc_pass(c, m.a, cc, bx_and(xhi, ylo), BCP_CORNER, dhx, dly, 0.0, nullptr));
+            if (!skip_corner(bc.hi[0]) && !skip_corner(bc.hi[1])) RH_TRY(bc_pass(c, m.a, cc, bx_and(xhi, yhi), BCP_CORNER, dhx, dhy, 0.0, nullptr));
         }
     }
     return 0;
 }
 
+// one side of a face-centred array, tangential to the faces (xvel :136-191, yvel :55-110): dir = the side's direction
+static int vel_tangential_side(rh_ctx *c, const MFV &m, const rh_array4 &msk, int comp, int dir, int hi, int type, double ext,
+                               rh_box r, int dl, int dh, const BcAux &aux)
+{
+    const int B = hi ? dh : dl, B2 = hi ? dh - 1 : dl + 1, G = hi ? dh + 1 : dl - 1;
+    const int cmode = dir == 0 ? BCP_COPY_I : BCP_COPY_J, fmode = dir == 0 ? BCP_FLIP_I : BCP_FLIP_J;
+    const int flip = hi ? 2 * dh + 1 : dl - 1;
+    if (type == RH_BC_EXT_DIR) return bc_pass(c, m.a, comp, r, BCP_CONST, 0, 0, ext, &msk);
+    if (type == RH_BC_FOEXTRAP || type == RH_BC_CLAMPED) return bc_pass(c, m.a, comp, r, cmode, B, B, 0.0, &msk);
+    if (type == RH_BC_ORLANSKI_RAD) { const OrlArgs o = {aux.calc, 0, nullptr, B, B2, G}; return bc_orlanski(c, m.a, comp, r, dir, hi, &msk, o); }
+    if (type == RH_BC_REFLECT_EVEN || type == RH_BC_REFLECT_ODD) return bc_pass(c, m.a, comp, r, fmode, flip, flip, type == RH_BC_REFLECT_ODD ? -1.0 : 1.0, &msk);
+    return 0;
+}
+// one side of a face-centred array, normal to the faces (xvel :56-134, yvel :112-192): the face line, then the ghost lines
+static int vel_normal_side(rh_ctx *c, const MFV &m, const rh_array4 &msk, int comp, int dir, int hi, int type, double ext,
+                           rh_box face, rh_box ghost, int dl, int dh, const BcAux &aux)
+{
+    const int cmode = dir == 0 ? BCP_COPY_I : BCP_COPY_J, fmode = dir == 0 ? BCP_FLIP_I : BCP_FLIP_J;
+    const int F = hi ? dh + 1 : dl;                       // the boundary face
+    const int in1 = hi ? dh : dl + 1, in2 = hi ? dh - 1 : dl + 2;
+    // the face itself: only ext_dir, actual outflow and radiation set it
+    if (type == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, face, BCP_CONST, 0, 0, ext, &msk));
+    else if (type == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, face, cmode, in1, in1, 0.0, &msk));
+    else if (type == RH_BC_ORLANSKI_RAD) {
+        // low side (:69-81): the wave leaves from the first interior face, blended with calc ON the boundary face;
+        // high side (:105-117): written like the cell-centred form, from face dom_hi (interior) towards dom_hi + 1
+        const OrlArgs o = {aux.calc, 0, nullptr, in1, in2, F};
+        RH_TRY(bc_orlanski(c, m.a, comp, face, dir, hi, &msk, o));
+    }
+    if (type == RH_BC_EXT_DIR) return bc_pass(c, m.a, comp, ghost, BCP_CONST, 0, 0, ext, &msk);
+    if (type == RH_BC_FOEXTRAP) return bc_pass(c, m.a, comp, ghost, cmode, in1, in1, 0.0, &msk);                       // inner = 1
+    if (type == RH_BC_CLAMPED || type == RH_BC_ORLANSKI_RAD) return bc_pass(c, m.a, comp, ghost, cmode, F, F, 0.0, &msk);   // inner = 0
+    if (type == RH_BC_REFLECT_EVEN || type == RH_BC_REFLECT_ODD) { const int fl = hi ? 2 * F : F; return bc_pass(c, m.a, comp, ghost, fmode, fl, fl, type == RH_BC_REFLECT_ODD ? -1.0 : 1.0, &msk); }   // :86,:121: dom_lo - i below, 2 (dom_hi + 1) - i above
+    return 0;
+}
+
 // REMORA_BoundaryConditions_xvel.cpp:12-269
-static int impose_xvel(rh_ctx *c, const MFV &m, const rh_array4 &msku, int comp, int bccomp)
+static int impose_xvel(rh_ctx *c, const MFV &m, const rh_array4 &msku, int comp, int bccomp, const BcAux &aux)
 {
     const rh_box dom = c->dom, bx = bx_of(m.a);
     const int perx = c->prm.periodic[0], pery = c->prm.periodic[1];
     const BCRec3 bc = setbc(c->bcs[bccomp], bx, dom); const double *ext = c->extdir[bccomp];
-    RH_TRY(supported(bc));
     const bool fx = (bccomp == RH_BCV_FOEXTRAP);
     if (!perx || fx) {                                                                           // :56-134
         rh_box xlo = bx; xlo.hi[0] = dom.lo[0] - 1; rh_box xhi = bx; xhi.lo[0] = dom.hi[0] + 2;
         rh_box flo = bx; flo.lo[0] = flo.hi[0] = dom.lo[0]; rh_box fhi = bx; fhi.lo[0] = fhi.hi[0] = dom.hi[0] + 1;
         xlo = bx_grow(xlo, 0, -1, 0); xhi = bx_grow(xhi, 0, -1, 0); flo = bx_grow(flo, 0, -1, 0); fhi = bx_grow(fhi, 0, -1, 0);
-        if (bc.lo[0] == RH_BC_EXT_DIR) { RH_TRY(bc_pass(c, m.a, comp, flo, BCP_CONST, 0, 0, ext[0], &msku)); RH_TRY(bc_pass(c, m.a, comp, xlo, BCP_CONST, 0, 0, ext[0], &msku)); }
-        else if (bc.lo[0] == RH_BC_FOEXTRAP) { RH_TRY(bc_pass(c, m.a, comp, flo, BCP_COPY_I, dom.lo[0] + 1, 0, 0.0, &msku)); RH_TRY(bc_pass(c, m.a, comp, xlo, BCP_COPY_I, dom.lo[0] + 1, 0, 0.0, &msku)); }
-        if (bc.hi[0] == RH_BC_EXT_DIR) { RH_TRY(bc_pass(c, m.a, comp, fhi, BCP_CONST, 0, 0, ext[3], &msku)); RH_TRY(bc_pass(c, m.a, comp, xhi, BCP_CONST, 0, 0, ext[3], &msku)); }
-        else if (bc.hi[0] == RH_BC_FOEXTRAP) { RH_TRY(bc_pass(c, m.a, comp, fhi, BCP_COPY_I, dom.hi[0], 0, 0.0, &msku)); RH_TRY(bc_pass(c, m.a, comp, xhi, BCP_COPY_I, dom.hi[0], 0, 0.0, &msku)); }
+        RH_TRY(vel_normal_side(c, m, msku, comp, 0, 0, bc.lo[0], ext[0], flo, xlo, dom.lo[0], dom.hi[0], aux));
+        RH_TRY(vel_normal_side(c, m, msku, comp, 0, 1, bc.hi[0], ext[3], fhi, xhi, dom.lo[0], dom.hi[0], aux));
     }
     if (!pery || fx) {                                                                           // :136-191
         rh_box ylo = bx; ylo.hi[1] = dom.lo[1] - 1; rh_box yhi = bx; yhi.lo[1] = dom.hi[1] + 1;
         ylo = bx_grow(ylo, -1, 0, 0); yhi = bx_grow(yhi, -1, 0, 0);
-        if (bc.lo[1] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, ylo, BCP_CONST, 0, 0, ext[1], &msku));
-        else if (bc.lo[1] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, ylo, BCP_COPY_J, 0, dom.lo[1], 0.0, &msku));
-        if (bc.hi[1] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, yhi, BCP_CONST, 0, 0, ext[4], &msku));
-        else if (bc.hi[1] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, yhi, BCP_COPY_J, 0, dom.hi[1], 0.0, &msku));
+        RH_TRY(vel_tangential_side(c, m, msku, comp, 1, 0, bc.lo[1], ext[1], ylo, dom.lo[1], dom.hi[1], aux));
+        RH_TRY(vel_tangential_side(c, m, msku, comp, 1, 1, bc.hi[1], ext[4], yhi, dom.lo[1], dom.hi[1], aux));
     }
     // z sides (:193-223): no ghost cells in z on this path
     if ((!perx || fx) && (!pery || fx)) {                                                        // :225-265
         rh_box xlo = bx; xlo.hi[0] = dom.lo[0]; rh_box xhi = bx; xhi.lo[0] = dom.hi[0] + 1;
         rh_box ylo = bx; ylo.hi[1] = dom.lo[1] - 1; rh_box yhi = bx; yhi.lo[1] = dom.hi[1] + 1;
-        RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, ylo), BCP_CORNER, dom.lo[0] + 1, dom.lo[1], 0.0, nullptr));
-        RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, yhi), BCP_CORNER, dom.lo[0] + 1, dom.hi[1], 0.0, nullptr));
-        RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, ylo), BCP_CORNER, dom.hi[0], dom.lo[1], 0.0, nullptr));
-        RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, yhi), BCP_CORNER, dom.hi[0], dom.hi[1], 0.0, nullptr));
+        // :236-239 ask the DOMAIN's types, not the box's
+        const BCRec3 &db = c->bcs[bccomp];
+        const bool cw = db.lo[0] == RH_BC_CLAMPED, ce = db.hi[0] == RH_BC_CLAMPED, cs = db.lo[1] == RH_BC_CLAMPED, cn = db.hi[1] == RH_BC_CLAMPED;
+        if (!cw && !cs) RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, ylo), BCP_CORNER, dom.lo[0] + 1, dom.lo[1], 0.0, nullptr));
+        if (!cw && !cn) RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, yhi), BCP_CORNER, dom.lo[0] + 1, dom.hi[1], 0.0, nullptr));
+        if (!ce && !cs) RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, ylo), BCP_CORNER, dom.hi[0], dom.lo[1], 0.0, nullptr));
+        if (!ce && !cn) RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, yhi), BCP_CORNER, dom.hi[0], dom.hi[1], 0.0, nullptr));
     }
     return 0;
 }
 
 // REMORA_BoundaryConditions_yvel.cpp:12-268
-static int impose_yvel(rh_ctx *c, const MFV &m, const rh_array4 &mskv, int comp, int bccomp)
+static int impose_yvel(rh_ctx *c, const MFV &m, const rh_array4 &mskv, int comp, int bccomp, const BcAux &aux)
 {
     const rh_box dom = c->dom, bx = bx_of(m.a);
     const int perx = c->prm.periodic[0], pery = c->prm.periodic[1];
     const BCRec3 bc = setbc(c->bcs[bccomp], bx, dom); const double *ext = c->extdir[bccomp];
-    RH_TRY(supported(bc));
     const bool fx = (bccomp == RH_BCV_FOEXTRAP);
     if (!perx || fx) {                                                                           // :55-110
         rh_box xlo = bx; xlo.hi[0] = dom.lo[0] - 1; rh_box xhi = bx; xhi.lo[0] = dom.hi[0] + 1;
         xlo = bx_grow(xlo, 0, -1, 0); xhi = bx_grow(xhi, 0, -1, 0);
-        if (bc.lo[0] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, xlo, BCP_CONST, 0, 0, ext[0], &mskv));
-        else if (bc.lo[0] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, xlo, BCP_COPY_I, dom.lo[0], 0, 0.0, &mskv));
-        if (bc.hi[0] == RH_BC_EXT_DIR) RH_TRY(bc_pass(c, m.a, comp, xhi, BCP_CONST, 0, 0, ext[3], &mskv));
-        else if (bc.hi[0] == RH_BC_FOEXTRAP) RH_TRY(bc_pass(c, m.a, comp, xhi, BCP_COPY_I, dom.hi[0], 0, 0.0, &mskv));
+        RH_TRY(vel_tangential_side(c, m, mskv, comp, 0, 0, bc.lo[0], ext[0], xlo, dom.lo[0], dom.hi[0], aux));
+        RH_TRY(vel_tangential_side(c, m, mskv, comp, 0, 1, bc.hi[0], ext[3], xhi, dom.lo[0], dom.hi[0], aux));
     }
     if (!pery || fx) {                                                                           // :112-192
         rh_box ylo = bx; ylo.hi[1] = dom.lo[1] - 1; rh_box yhi = bx; yhi.lo[1] = dom.hi[1] + 2;
         rh_box flo = bx; flo.lo[1] = flo.hi[1] = dom.lo[1]; rh_box fhi = bx; fhi.lo[1] = fhi.hi[1] = dom.hi[1] + 1;
         ylo = bx_grow(ylo, -1, 0, 0); yhi = bx_grow(yhi, -1, 0, 0); flo = bx_grow(flo, -1, 0, 0); fhi = bx_grow(fhi, -1, 0, 0);
-        if (bc.lo[1] == RH_BC_EXT_DIR) { RH_TRY(bc_pass(c, m.a, comp, flo, BCP_CONST, 0, 0, ext[1], &mskv)); RH_TRY(bc_pass(c, m.a, comp, ylo, BCP_CONST, 0, 0, ext[1], &mskv)); }
-        else if (bc.lo[1] == RH_BC_FOEXTRAP) { RH_TRY(bc_pass(c, m.a, comp, flo, BCP_COPY_J, 0, dom.lo[1] + 1, 0.0, &mskv)); RH_TRY(bc_pass(c, m.a, comp, ylo, BCP_COPY_J, 0, dom.lo[1] + 1, 0.0, &mskv)); }
-        if (bc.hi[1] == RH_BC_EXT_DIR) { RH_TRY(bc_pass(c, m.a, comp, fhi, BCP_CONST, 0, 0, ext[4], &mskv)); RH_TRY(bc_pass(c, m.a, comp, yhi, BCP_CONST, 0, 0, ext[4], &mskv)); }
-        else if (bc.hi[1] == RH_BC_FOEXTRAP) { RH_TRY(bc_pass(c, m.a, comp, fhi, BCP_COPY_J, 0, dom.hi[1], 0.0, &mskv)); RH_TRY(bc_pass(c, m.a, comp, yhi, BCP_COPY_J, 0, dom.hi[1], 0.0, &mskv)); }
+        RH_TRY(vel_normal_side(c, m, mskv, comp, 1, 0, bc.lo[1], ext[1], flo, ylo, dom.lo[1], dom.hi[1], aux));
+        RH_TRY(vel_normal_side(c, m, mskv, comp, 1, 1, bc.hi[1], ext[4], fhi, yhi, dom.lo[1], dom.hi[1], aux));
     }
     if ((!perx || fx) && (!pery || fx)) {                                                        // :226-265
         rh_box xlo = bx; xlo.hi[0] = dom.lo[0] - 1; rh_box xhi = bx; xhi.lo[0] = dom.hi[0] + 1;
         rh_box ylo = bx; ylo.hi[1] = dom.lo[1]; rh_box yhi = bx; yhi.lo[1] = dom.hi[1] + 1;
-        RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, ylo), BCP_CORNER, dom.lo[0], dom.lo[1] + 1, 0.0, nullptr));
-        RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, yhi), BCP_CORNER, dom.lo[0], dom.hi[1], 0.0, nullptr));
-        RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, ylo), BCP_CORNER, dom.hi[0], dom.lo[1] + 1, 0.0, nullptr));
-        RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, yhi), BCP_CORNER, dom.hi[0], dom.hi[1], 0.0, nullptr));
+        const BCRec3 &db = c->bcs[bccomp];
+        const bool cw = db.lo[0] == RH_BC_CLAMPED, ce = db.hi[0] == RH_BC_CLAMPED, cs = db.lo[1] == RH_BC_CLAMPED, cn = db.hi[1] == RH_BC_CLAMPED;
+        if (!cw && !cs) RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, ylo), BCP_CORNER, dom.lo[0], dom.lo[1] + 1, 0.0, nullptr));
+        if (!cw && !cn) RH_TRY(bc_pass(c, m.a, comp, bx_and(xlo, yhi), BCP_CORNER, dom.lo[0], dom.hi[1], 0.0, nullptr));
+        if (!ce && !cs) RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, ylo), BCP_CORNER, dom.hi[0], dom.lo[1] + 1, 0.0, nullptr));
+        if (!ce && !cn) RH_TRY(bc_pass(c, m.a, comp, bx_and(xhi, yhi), BCP_CORNER, dom.hi[0], dom.hi[1], 0.0, nullptr));
     }
     return 0;
 }
@@ -584,7 +714,7 @@ static int impose_zvel(rh_ctx *c, const MFV &m, int comp, int bccomp)
 }
 
 // REMORA_PhysBCFunct.cpp:21-93
-static int physbc_impl(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill)
+static int physbc_impl(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill, const BcAux &aux)
 {
     rh_box gdom = c->dom;
     for (int d = 0; d < 3; d++) if (m.ix[d]) gdom.hi[d] += 1;
@@ -594,25 +724,28 @@ static int physbc_impl(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp,
     gdom.lo[2] = bx.lo[2]; gdom.hi[2] = bx.hi[2];
     if (bx_contains(gdom, bx)) return 0;
     if (icomp < 0 || icomp + ncomp > m.a.ncomp) return rh_fail("halo_physbc: component range");
-    if (!m.ix[0] && !m.ix[1] && !m.ix[2]) return impose_cons(c, m, msk, icomp, ncomp, bccomp, n_not_fill);
+    if (!m.ix[0] && !m.ix[1] && !m.ix[2]) return impose_cons(c, m, msk, icomp, ncomp, bccomp, n_not_fill, aux);
     if (ncomp != 1) return rh_fail("halo_physbc: velocity BCs take one component");
-    if (m.ix[0]) return impose_xvel(c, m, msk, icomp, bccomp);
-    if (m.ix[1]) return impose_yvel(c, m, msk, icomp, bccomp);
+    if (m.ix[0]) return impose_xvel(c, m, msk, icomp, bccomp, aux);
+    if (m.ix[1]) return impose_yvel(c, m, msk, icomp, bccomp, aux);
     return impose_zvel(c, m, icomp, bccomp);
 }
 
-int halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill)
+int halo_physbc(rh_ctx *c, const MFV &m, const rh_array4 &msk, int icomp, int ncomp, int bccomp, int n_not_fill,
+                const rh_array4 *calc, const rh_array4 *msku, const rh_array4 *mskv)
 {
     BcScope bcs(c);                                       // all components' passes of one call share the launches
-    RH_TRY(physbc_impl(c, m, msk, icomp, ncomp, bccomp, n_not_fill));
+    const BcAux aux = {calc, msku, mskv};
+    RH_TRY(physbc_impl(c, m, msk, icomp, ncomp, bccomp, n_not_fill, aux));
     return bcs.end();
 }
 
-// REMORA::FillPatch at level 0 (BoundaryConditions/REMORA_FillPatch.cpp:96-125) == FillBoundary + physbc
-int halo_fillpatch(rh_ctx *c, const MFV &m, const rh_array4 &msk, int bccomp, int icomp, int ncomp)
+// REMORA::FillPatch at level 0 (BoundaryConditions/REMORA_FillPatch.cpp:96-129) == FillBoundary + physbc
+int halo_fillpatch(rh_ctx *c, const MFV &m, const rh_array4 &msk, int bccomp, int icomp, int ncomp,
+                   const rh_array4 *calc, const rh_array4 *msku, const rh_array4 *mskv)
 {
     RH_TRY(halo_fill_boundary(c, m, icomp, ncomp));
-    return halo_physbc(c, m, msk, icomp, ncomp, bccomp, 0);
+    return halo_physbc(c, m, msk, icomp, ncomp, bccomp, 0, calc, msku, mskv);
 }
 
 // ---- C ABI -----------------------------------------------------------------------------------------------------
@@ -631,3 +764,15 @@ extern "C" int rh_physbc(rh_ctx *c, rh_array4 a, const int ng[3], rh_array4 msk,
 { TScope t(c, "physbc"); return halo_physbc(c, mfv_from_ng(c, a, ng), msk, icomp, ncomp, bccomp, 0); }
 extern "C" int rh_fill_patch(rh_ctx *c, rh_array4 a, const int ng[3], rh_array4 msk, int bccomp, int icomp, int ncomp)
 { TScope t(c, "fill_patch"); return halo_fillpatch(c, mfv_from_ng(c, a, ng), msk, bccomp, icomp, ncomp); }
+extern "C" int rh_physbc_calc(rh_ctx *c, rh_array4 a, const int ng[3], rh_array4 msk, int icomp, int ncomp, int bccomp, int n_not_fill,
+                              rh_array4 calc, rh_array4 msku, rh_array4 mskv)
+{
+    TScope t(c, "physbc");
+    return halo_physbc(c, mfv_from_ng(c, a, ng), msk, icomp, ncomp, bccomp, n_not_fill, calc.p ? &calc : nullptr, msku.p ? &msku : nullptr, mskv.p ? &mskv : nullptr);
+}
+extern "C" int rh_fill_patch_calc(rh_ctx *c, rh_array4 a, const int ng[3], rh_array4 msk, int bccomp, int icomp, int ncomp,
+                                  rh_array4 calc, rh_array4 msku, rh_array4 mskv)
+{
+    TScope t(c, "fill_patch");
+    return halo_fillpatch(c, mfv_from_ng(c, a, ng), msk, bccomp, icomp, ncomp, calc.p ? &calc : nullptr, msku.p ? &msku : nullptr, mskv.p ? &mskv : nullptr);
+}

@@ -124,6 +124,10 @@ SIGNATURES = {
     "rh_fill_boundary": (C.c_int, [_P, _A, C.c_int * 3, C.c_int, C.c_int]),
     "rh_physbc": (C.c_int, [_P, _A, C.c_int * 3, _A, C.c_int, C.c_int, C.c_int]),
     "rh_fill_patch": (C.c_int, [_P, _A, C.c_int * 3, _A, C.c_int, C.c_int, C.c_int]),
+    "rh_physbc_calc": (C.c_int, [_P, _A, C.c_int * 3, _A, C.c_int, C.c_int, C.c_int, C.c_int, _A, _A, _A]),
+    "rh_fill_patch_calc": (C.c_int, [_P, _A, C.c_int * 3, _A, C.c_int, C.c_int, C.c_int, _A, _A, _A]),
+    "rh_set_bc": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "rh_get_bc": (C.c_int, [_P, C.c_int, C.c_int * 6]),
     "rh_stretch_transform": (C.c_int, [_P, _SP]),
     "rh_rho_eos": (C.c_int, [_P, Box] + [_A] * 10 + [C.c_int]),
     "rh_prsgrd": (C.c_int, [_P, Box, Box, Box] + [_A] * 11 + [C.c_int, C.c_int]),

@@ -97,6 +97,12 @@ class REMORA:
         self.ctx = C.c_void_p()
         self.stream = stream
         L.check(self.lib.rh_create(C.byref(self.params), C.c_void_p(stream.cuda_stream if stream is not None else 0), C.byref(self.ctx)))
+        # bc.<var>.type / bc.<side>.type of the inputs file (REMORA::init_bcs): everything that is not periodic / SlipWall
+        if "bc" in case:
+            from .cases import PBC, BC_VARS
+            for iv, var in enumerate(BC_VARS):
+                for face, word in case["bc"][var].items():
+                    L.check(self.lib.rh_set_bc(self.ctx, iv, face, PBC[word], float(case.get("bc_val", {}).get(var, {}).get(face, 0.0))))
         nbytes = self.lib.rh_state_bytes(self.ctx)
         self.buf = torch.zeros(nbytes // 8 + 32, dtype=torch.float64, device=self.device)
         base = (self.buf.data_ptr() + 255) // 256 * 256
