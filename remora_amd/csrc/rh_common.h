@@ -156,6 +156,11 @@ struct rh_ctx {
     hipStream_t own_xstream = nullptr;                         // the side stream this context created (never swapped; rh_destroy frees this one only)
     hipStream_t xstream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_comm = nullptr;
     double *d_xbuf2 = nullptr; long xcap2 = 0;
+    // barotropic loop of a decomposed run (rh_step2d.hip): the new level's ghost fill of call n is owed until call n + 1 has put its
+    // interior tiles on the compute stream; it then runs on the side stream, under them
+    struct { bool on = false; rh_array4 ubar, vbar, zeta, msku, mskv, mskr; int knew = 0; } pend2d;
+    hipEvent_t ev2d_m = nullptr, ev2d_b = nullptr;
+    bool in_loop2d = false, no_split2d = false;                // RH_NO_SPLIT2D=1: never split k2d_fused into interior and rim launches
     bool async_on = false, async_pending = false, in_advance = false, no_async = false, async_rccl = false;
     hipStream_t last_comm_stream = nullptr; bool comm_used = false;
     // per-kernel-group timing
@@ -197,6 +202,9 @@ int  halo_flush(rh_ctx *c);
 int  halo_async_begin(rh_ctx *c);
 int  halo_async_end(rh_ctx *c);
 int  halo_async_join(rh_ctx *c);
+int  halo_side_enter(rh_ctx *c);     // the following launches, messages and BC passes go to the side stream ...
+int  halo_side_leave(rh_ctx *c);     // ... until here (no events: the caller orders the two streams)
+int  step2d_flush_pending(rh_ctx *c);   // the owed ghost fill of the barotropic loop, on the current stream
 // Ghost exchanges and BC passes issued between bc_begin and the matching bc_end are queued and flushed as one launch per dependency level; only
 // ghost-fill calls may sit inside such a scope (any other kernel on the same arrays would overtake the queued passes)
 void bc_begin(rh_ctx *c);

@@ -13,7 +13,7 @@ int rh_fail(const char *fmt, ...)
     return 1;
 }
 extern "C" const char *rh_last_error(void) { return g_rh_err.c_str(); }
-#define RH_BUILD_ID "r2_v6"
+#define RH_BUILD_ID "r2_v7"
 extern "C" const char *rh_build_id(void) { return RH_BUILD_ID; }
 
 // ------------------------------------------------------------------------------------------------ timing
@@ -425,6 +425,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     c->gls_libm_pow = getenv("RH_GLS_LIBM_POW") && atoi(getenv("RH_GLS_LIBM_POW")) != 0;
     c->no_async = getenv("RH_NO_ASYNC") && atoi(getenv("RH_NO_ASYNC")) != 0;
     c->async_rccl = getenv("RH_ASYNC_RCCL") && atoi(getenv("RH_ASYNC_RCCL")) != 0;
+    c->no_split2d = getenv("RH_NO_SPLIT2D") && atoi(getenv("RH_NO_SPLIT2D")) != 0;
     c->no_bc2d = getenv("RH_NO_BC2D") && atoi(getenv("RH_NO_BC2D")) != 0;
     c->poison = getenv("RH_POISON") && atoi(getenv("RH_POISON")) != 0;
 
@@ -481,7 +482,7 @@ extern "C" int rh_destroy(rh_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     // only the stream this context created is destroyed, whatever c->stream / c->xstream point at
     if (c->own_xstream) { (void)hipStreamSynchronize(c->own_xstream); (void)hipStreamDestroy(c->own_xstream); }
-    for (hipEvent_t e : {c->ev_fork, c->ev_join, c->ev_comm}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {c->ev_fork, c->ev_join, c->ev_comm, c->ev2d_m, c->ev2d_b}) if (e) (void)hipEventDestroy(e);
     if (c->d_xbuf2) (void)hipFree(c->d_xbuf2);
     for (auto &v : c->tev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &e : c->evpool) (void)hipEventDestroy(e);

@@ -240,7 +240,13 @@ extern "C" int rh_advance(rh_ctx *c, rh_state *s, int istep, double t_old)
     RH_TRY(rc0);
     if (c->prm.use_barotropic) {
         const int nfast_counter = c->nfast + 1;
-        for (int my_iif = 0; my_iif < nfast_counter; my_iif++) RH_TRY(rh_advance_2d_onestep(c, s, istep, my_iif));
+        // inside this loop a decomposed run may leave the new level's ghost fill owed from one call to the next (rh_step2d.hip);
+        // rh_advance_3d_ml's join settles the last one
+        c->in_loop2d = true;
+        int rc = 0;
+        for (int my_iif = 0; my_iif < nfast_counter && !rc; my_iif++) rc = rh_advance_2d_onestep(c, s, istep, my_iif);
+        c->in_loop2d = false;
+        if (rc) { c->pend2d.on = false; return rc; }
     }
     return rh_advance_3d_ml(c, s, istep);
 }

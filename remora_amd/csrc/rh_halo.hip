@@ -253,6 +253,7 @@ static void async_swap(rh_ctx *c)
 {
     std::swap(c->stream, c->xstream); std::swap(c->d_xbuf, c->d_xbuf2); std::swap(c->xcap, c->xcap2);
 }
+static int side_stream_ensure(rh_ctx *c);
 int halo_async_begin(rh_ctx *c)
 {
     if (c->no_async || c->async_on) return 0;
@@ -262,11 +263,7 @@ int halo_async_begin(rh_ctx *c)
     if (c->comm && !c->async_rccl) return 0;
     RH_TRY(bc_flush(c));
     RH_TRY(halo_async_join(c));                          // one scope in flight at a time
-    if (!c->xstream) {
-        RH_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
-        c->own_xstream = c->xstream;
-        RH_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); RH_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
-    }
+    RH_TRY(side_stream_ensure(c));
     RH_HIP(hipEventRecord(c->ev_fork, c->stream));
     RH_HIP(hipStreamWaitEvent(c->xstream, c->ev_fork, 0));
     async_swap(c); c->async_on = true;
@@ -282,8 +279,32 @@ int halo_async_end(rh_ctx *c)
     RH_HIP(e);
     return 0;
 }
+static int side_stream_ensure(rh_ctx *c)
+{
+    if (c->xstream) return 0;
+    RH_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    c->own_xstream = c->xstream;
+    RH_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); RH_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    return 0;
+}
+int halo_side_enter(rh_ctx *c)
+{
+    if (c->async_on) return rh_fail("halo_side_enter: a side-stream scope is already open");
+    RH_TRY(bc_flush(c));
+    RH_TRY(side_stream_ensure(c));
+    async_swap(c); c->async_on = true;
+    return 0;
+}
+int halo_side_leave(rh_ctx *c)
+{
+    if (!c->async_on) return 0;
+    const int rc = bc_flush(c);
+    async_swap(c); c->async_on = false;
+    return rc;
+}
 int halo_async_join(rh_ctx *c)
 {
+    RH_TRY(step2d_flush_pending(c));
     if (!c->async_pending) return 0;
     c->async_pending = false;
     RH_HIP(hipStreamWaitEvent(c->stream, c->ev_join, 0));

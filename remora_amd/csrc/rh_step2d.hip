@@ -347,7 +347,8 @@ struct B2v { int lo0, lo1, hi0, hi1; };      // the rank's valid cell box; every
 // takes ONE struct and the later phases read their scalars again from the kernel-argument segment (scalar loads, served by the
 // scalar cache) through a pointer the compiler cannot trace back to the argument, so nothing has to stay live from phase to phase.
 struct K2Args { B2v vb; UVPar P; ZetaPar zp; K2Arrays A; int ghost_from_mem; int ntile_x, ntile_y, nframe;
-                double bc_ext[4]; int wallbc; };   // wallbc: all four sides are walls of a one-rank domain: the blocks on the rim also write the ghost cells of the new level (bc_ext: ubar x-lo / x-hi, vbar y-lo / y-hi ext_dir values)    // the launch's first nframe blocks (in tile order) carry the ghost frame, the next ntile_x * ntile_y are tiles
+                double bc_ext[4]; int wallbc;
+                int part; };       // 0: every tile; 1: interior tiles only; 2: rim tiles only (see k2_tile_is_interior)   // wallbc: all four sides are walls of a one-rank domain: the blocks on the rim also write the ghost cells of the new level (bc_ext: ubar x-lo / x-hi, vbar y-lo / y-hi ext_dir values)    // the launch's first nframe blocks (in tile order) carry the ghost frame, the next ntile_x * ntile_y are tiles
 __device__ __forceinline__ const K2Args &k2_args_again()
 {
     typedef const K2Args __attribute__((address_space(4))) *KP;
@@ -404,6 +405,11 @@ __device__ __forceinline__ void k2_frame_point(const K2Args &L, int g)
         if (iny) DV_avg2(i, j, 0) = DV_avg2(i, j, 0) + zp.wt_b * dv;
     }
 }
+// A tile is interior when everything it stages (its footprint of F_PX x F_PY points from (I0 - 2, J0 - 2)) lies at least three
+// cells inside the rank's valid box: it then reads no ghost cell, no shared face and nothing within reach of the ghost exchange,
+// and may run while the exchanges of this call and the ghost fill of the previous one are still in flight.
+__host__ __device__ __forceinline__ bool k2_tile_is_interior(const B2v &vb, int I0, int J0)
+{ return I0 - 2 >= vb.lo0 + 3 && I0 - 2 + F_PX - 1 <= vb.hi0 - 3 && J0 - 2 >= vb.lo1 + 3 && J0 - 2 + F_PY - 1 <= vb.hi1 - 3; }
 __global__ void __launch_bounds__(RT_BX * U_BY)
 k2d_fused(K2Args a0)
 {
@@ -439,6 +445,7 @@ k2d_fused(K2Args a0)
     const int tile_x = lin % a0.ntile_x, tile_y = lin / a0.ntile_x;
     if (tile_y >= a0.ntile_y) return;
     const int I0 = un.lo0 - 1 + tile_x * U_SX, J0 = un.lo1 - 1 + tile_y * U_SY;
+    if (a0.part && (a0.part == 1) != k2_tile_is_interior(vb, I0, J0)) return;      // uniform over the block
     const int i = I0 + tx, j = J0 + ty;
     const bool in_rb = inb2(rb, i, j), in_un = inb2(un, i, j);
     const bool owner = in_rb && (tx >= 1 || tile_x == 0) && (ty >= 1 || tile_y == 0);
@@ -947,6 +954,7 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
     // FillBoundary of DUon / DVom has work to do only in a periodic direction or next to a neighbour rank
     const bool fb_work = c->prm.periodic[0] || c->prm.periodic[1] || c->prm.nranks[0] > 1 || c->prm.nranks[1] > 1;
     const rh_box hole = bx_grow(b2, -3, -3, 0);
+    auto flux_exchange = [&]() -> int {
     if (!fused || fb_work) {
         if (!fused || !bx_ok(hole))
             k2d_flux<<<grid2(tbxp3), rh_block(), 0, c->stream>>>(mkB(tbxp3), mkB(xgbx2), mkB(ygbx2), mkA(zeta_rhs), mkA(s->h), mkA(ub_rhs), mkA(vb_rhs),
@@ -962,6 +970,19 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
         RH_TRY(halo_fill_boundary(c, mfv(c, c->DVom, 0, 1, 0), 0, 1));
         RH_TRY(xs.end());
     }
+    return 0; };
+    // Decomposed run inside rh_advance's barotropic loop: the interior tiles of k2d_fused go to the compute stream first; the side
+    // stream then runs the ghost fill the previous call left owed, this call's flux frame and the DUon / DVom exchange under them;
+    // the rim tiles wait for that; the new level's ghost fill is left owed to the next call (or to the join in rh_advance_3d_ml).
+    bool split = fused && c->in_loop2d && !c->no_async && !c->no_split2d && (c->prm.nranks[0] > 1 || c->prm.nranks[1] > 1) &&
+                 (c->xfn || (c->comm && c->async_rccl)) && bx_ok(hole);
+    if (split) {                                             // at least one interior tile, or the split only costs a launch
+        const rh_box un0 = bx_union(xbxD, ybxD);
+        const int ntx = (un0.hi[0] - un0.lo[0] + U_SX) / U_SX, nty = (un0.hi[1] - un0.lo[1] + U_SY) / U_SY;
+        const B2v vb0{b2.lo[0], b2.lo[1], b2.hi[0], b2.hi[1]};
+        split = ntx >= 3 && nty >= 3 && k2_tile_is_interior(vb0, un0.lo[0] - 1 + (ntx / 2) * U_SX, un0.lo[1] - 1 + (nty / 2) * U_SY);
+    }
+    if (!split) { RH_TRY(step2d_flush_pending(c)); RH_TRY(flux_exchange()); }
 
     // ---- averages + free surface
     ZetaPar zp; memset(&zp, 0, sizeof zp);
@@ -1030,8 +1051,32 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
             K2Args ka; ka.vb = vbx; ka.P = P; ka.zp = zp; ka.A = KA; ka.ghost_from_mem = fb_work ? 1 : 0; ka.ntile_x = (int)grid.x; ka.ntile_y = (int)grid.y; ka.nframe = nfb;
             ka.wallbc = wallbc ? 1 : 0;
             ka.bc_ext[0] = c->extdir[RH_BCV_UBAR][0]; ka.bc_ext[1] = c->extdir[RH_BCV_UBAR][3]; ka.bc_ext[2] = c->extdir[RH_BCV_VBAR][1]; ka.bc_ext[3] = c->extdir[RH_BCV_VBAR][4];
-            { TScope tk(c, "k2d_fused"); k2d_fused<<<dim3(grid.x, grid.y + (unsigned)frame_rows, 1), dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ka); }
-            RH_LAUNCH_CHECK();
+            ka.part = 0;
+            if (!split) {
+                { TScope tk(c, "k2d_fused"); k2d_fused<<<dim3(grid.x, grid.y + (unsigned)frame_rows, 1), dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ka); }
+                RH_LAUNCH_CHECK();
+            } else {
+                if (!c->ev2d_m) { RH_HIP(hipEventCreateWithFlags(&c->ev2d_m, hipEventDisableTiming)); RH_HIP(hipEventCreateWithFlags(&c->ev2d_b, hipEventDisableTiming)); }
+                RH_HIP(hipEventRecord(c->ev2d_m, c->stream));                    // everything up to the previous call's rim tiles
+                K2Args ki = ka; ki.part = 1; ki.nframe = 0;
+                { TScope tk(c, "k2d_fused"); k2d_fused<<<dim3(grid.x, grid.y, 1), dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ki); }
+                RH_LAUNCH_CHECK();
+                RH_TRY(halo_side_enter(c));                                       // c->stream is the side stream from here ...
+                int rc = 0;
+                if (hipStreamWaitEvent(c->stream, c->ev2d_m, 0) != hipSuccess) rc = rh_fail("rh_advance_2d: hipStreamWaitEvent failed");
+                if (!rc) rc = step2d_flush_pending(c);
+                if (!rc) rc = flux_exchange();
+                if (!rc && hipEventRecord(c->ev2d_b, c->stream) != hipSuccess) rc = rh_fail("rh_advance_2d: hipEventRecord failed");
+                const int rc2 = halo_side_leave(c);                               // ... to here
+                RH_TRY(rc); RH_TRY(rc2);
+                RH_HIP(hipStreamWaitEvent(c->stream, c->ev2d_b, 0));
+                ka.part = 2;
+                { TScope tk(c, "k2d_fused"); k2d_fused<<<dim3(grid.x, grid.y + (unsigned)frame_rows, 1), dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ka); }
+                RH_LAUNCH_CHECK();
+                c->pend2d.on = true; c->pend2d.ubar = s->ubar; c->pend2d.vbar = s->vbar; c->pend2d.zeta = s->zeta;
+                c->pend2d.msku = s->msku; c->pend2d.mskv = s->mskv; c->pend2d.mskr = s->mskr; c->pend2d.knew = knew;
+                return 0;
+            }
         } else
         k2d_uvbar<<<grid, dim3(RT_BX, U_BY, 1), 0, c->stream>>>(mkB(xbxD), mkB(ybxD), mkB(un), mkB(tbxp1), P, mkA(ub_rhs), mkA(vb_rhs),
             mkA(a4_comp(s->ubar, kstp)), mkA(a4_comp(s->vbar, kstp)), mkA(a4_comp(s->ubar, knew)), mkA(a4_comp(s->vbar, knew)),
@@ -1048,6 +1093,19 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
     RH_TRY(halo_fillpatch(c, mfv(c, s->ubar, 1, 0, 0), s->msku, RH_BCV_UBAR, knew, 1));
     RH_TRY(halo_fillpatch(c, mfv(c, s->vbar, 0, 1, 0), s->mskv, RH_BCV_VBAR, knew, 1));
     RH_TRY(halo_fillpatch(c, mfv(c, s->zeta, 0, 0, 0), s->mskr, RH_BCV_ZETA, knew, 1));
+    return bcs.end();
+}
+
+// the ghost cells of the new time level (:735-755) that a split call left owed; runs on whatever stream the context points at
+int step2d_flush_pending(rh_ctx *c)
+{
+    if (!c->pend2d.on) return 0;
+    c->pend2d.on = false;
+    const int knew = c->pend2d.knew;
+    BcScope bcs(c);
+    RH_TRY(halo_fillpatch(c, mfv(c, c->pend2d.ubar, 1, 0, 0), c->pend2d.msku, RH_BCV_UBAR, knew, 1));
+    RH_TRY(halo_fillpatch(c, mfv(c, c->pend2d.vbar, 0, 1, 0), c->pend2d.mskv, RH_BCV_VBAR, knew, 1));
+    RH_TRY(halo_fillpatch(c, mfv(c, c->pend2d.zeta, 0, 0, 0), c->pend2d.mskr, RH_BCV_ZETA, knew, 1));
     return bcs.end();
 }
 

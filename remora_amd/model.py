@@ -147,21 +147,25 @@ class REMORA:
         """Transport hook that stages every message through the host and torch.distributed send/recv (any backend, e.g.
         gloo).  For tests of the decomposition on boxes without one GPU per rank; RCCL is the production transport."""
         hip = C.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        # copies go through the stream the library hands over (hipMemcpy would order itself behind the compute stream's kernels when
+        # that is the null stream, and the exchange could never run under them)
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         hip.hipStreamSynchronize.argtypes = [C.c_void_p]
         torch = self.torch
 
         def xfn(user, s_lo, r_lo, n_lo, p_lo, s_hi, r_hi, n_hi, p_hi, stream):
             try:
-                if hip.hipStreamSynchronize(stream) != 0:
-                    return 2
-                reqs, recvs = [], []
+                reqs, recvs, sends = [], [], []
                 for sp, n, peer, tag in ((s_lo, n_lo, p_lo, 0), (s_hi, n_hi, p_hi, 1)):      # tag 0: travels down, 1: up
                     if peer >= 0 and n > 0:
                         h = torch.empty(n, dtype=torch.float64)
-                        if hip.hipMemcpy(h.data_ptr(), sp, n * 8, 2) != 0:
+                        if hip.hipMemcpyAsync(h.data_ptr(), sp, n * 8, 2, stream) != 0:
                             return 3
-                        reqs.append(dist.isend(h, dst=peer, tag=tag))
+                        sends.append((h, peer, tag))
+                if hip.hipStreamSynchronize(stream) != 0:
+                    return 2
+                for h, peer, tag in sends:
+                    reqs.append(dist.isend(h, dst=peer, tag=tag))
                 for rp, n, peer, tag in ((r_hi, n_hi, p_hi, 0), (r_lo, n_lo, p_lo, 1)):      # from above arrives what went down
                     if peer >= 0 and n > 0:
                         h = torch.empty(n, dtype=torch.float64)
@@ -170,8 +174,10 @@ class REMORA:
                 for q in reqs:
                     q.wait()
                 for rp, h, n in recvs:
-                    if hip.hipMemcpy(rp, h.data_ptr(), n * 8, 1) != 0:
+                    if hip.hipMemcpyAsync(rp, h.data_ptr(), n * 8, 1, stream) != 0:
                         return 4
+                if recvs and hip.hipStreamSynchronize(stream) != 0:          # the host buffers go away on return
+                    return 2
                 return 0
             except Exception as e:                                      # never let an exception cross the C boundary
                 print("host transport failed:", repr(e), flush=True)

@@ -36,7 +36,12 @@ def main():
     case, nsteps = sys.argv[1], int(sys.argv[2])
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    cfg = cases.get(case)
+    # "Case@NXxNYxNZ": the case's physics on a finer grid (cases.scaled), for boxes wide enough to have interior tiles
+    if "@" in case:
+        case, dims = case.split("@")
+        cfg = cases.scaled(case, tuple(int(x) for x in dims.split("x")))
+    else:
+        cfg = cases.get(case)
     nx, ny, nz = cfg["ncell"]
     px, py = (int(x) for x in sys.argv[3].split("x")) if len(sys.argv) > 3 else (1, world)
     assert px * py == world
@@ -63,7 +68,15 @@ def main():
             for q in range(ncalls):
                 r.advance_2d_onestep(q)
         r.sync()
+    if os.environ.get("REMORA_DECOMP_EXPECT_SPLIT", ""):
+        rem.timing(True)
     run(rem)
+    if os.environ.get("REMORA_DECOMP_EXPECT_SPLIT", ""):
+        # the interior / rim split of k2d_fused is in force: two launches of the kernel per fused barotropic call
+        rep = rem.timing_report(); rem.timing(False)
+        per_step = 2 * rem.nfast                            # predictor and corrector of my_iif = 0 .. nfast - 1
+        want = {"1": 2, "0": 1}[os.environ["REMORA_DECOMP_EXPECT_SPLIT"]] * per_step * nsteps
+        assert rep["k2d_fused"]["calls"] == want, (rep["k2d_fused"], want)
     mine = {}
     fields = FIELDS + (["tke", "gls", "Lscale", "Akk", "Akp", "Akt"] if "gls" in cfg else [])
     for f in fields:

@@ -23,6 +23,23 @@ def test_decomposed_equals_single_box(case, world, port, grid):
     assert r.returncode == 0 and "DECOMP_OK" in out, out[-4000:]
 
 
+@pytest.mark.parametrize("split", ["1", "0"])
+@pytest.mark.parametrize("case,world,port,grid", [("DoubleGyre@420x100x4", 2, 29651, "2x1"), ("Upwelling@300x210x6", 2, 29652, "1x2"),
+                                                  ("DoubleGyre@420x210x4", 4, 29653, "2x2"), ("Seamount@300x210x5", 3, 29654, "1x3")])
+def test_interior_rim_split_keeps_the_bits(case, world, port, grid, split):
+    """Boxes wide enough for k2d_fused to have interior tiles (>= 3 tiles of 63 x 7 points each way): inside rh_advance the barotropic
+    loop then launches the interior tiles first, runs the flux frame, the DUon / DVom exchange and the previous call's ghost fill on
+    the side stream under them, and the rim tiles last.  The worker asserts the launch count (two k2d_fused launches per fused call
+    with the split, one with RH_NO_SPLIT2D=1) and the usual bit-identity with the single-box run."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", REMORA_DECOMP_EXPECT_SPLIT=split,
+               RH_NO_SPLIT2D="0" if split == "1" else "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port + (10 if split == "0" else 0)), os.path.join(ROOT, "tests", "decomp_worker.py"), case, "2", grid]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "DECOMP_OK" in out, out[-4000:]
+
+
 def _ngpu():
     import torch
     return torch.cuda.device_count()
