@@ -60,6 +60,17 @@ void REMORA::rh_make_context (int lev)
     p.masks_all_one = 0;                      // REMORA may carry land masks (NetCDF grids): keep the final cons *= mskr pass
     if (m_rh.size() <= static_cast<std::size_t>(lev)) m_rh.resize(lev + 1, nullptr);
     RH_CALL(rh_create(&p, (void*)Gpu::gpuStream(), &m_rh[lev]));
+    // REMORA::init_bcs has run (REMORA.cpp: constructor -> init_bcs): hand its phys_bc_type over, one variable and lateral face at a
+    // time.  RH_PBC_* follows enum struct REMORA_BC (REMORA_IndexDefines.H:53-56) and the variable index follows BCVars, so both
+    // casts are the identity; the library redoes the translation of init_bcs.cpp:201-679 itself (rh_get_bc reads it back: a
+    // maintainer can assert it equals domain_bcs_type).  Inflow / no-slip values travel as m_bc_extdir_vals.
+    for (int v = 0; v <= BCVars::tke_bc; ++v) {
+        for (OrientationIter oit; oit; ++oit) {
+            const Orientation ori = oit();
+            if (ori.coordDir() == 2) continue;                                 // z faces are SlipWall by construction (init_bcs.cpp:130)
+            RH_CALL(rh_set_bc(m_rh[lev], v, static_cast<int>(ori), static_cast<int>(phys_bc_type[v][ori]), m_bc_extdir_vals[v][ori]));
+        }
+    }
     if (ParallelDescriptor::NProcs() > 1)
         RH_CALL(rh_comm_set_exchange(m_rh[lev], rh_mpi_exchange, nullptr, ParallelDescriptor::MyProc(), ParallelDescriptor::NProcs()));
     nfast = rh_nfast(m_rh[lev]);                                               // REMORA::set_weights, REMORA_set_weights.cpp:10-171
