@@ -1088,16 +1088,17 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
     double frcu = au ? rufrc(i, j, 0) : 0.0, frcv = av ? rvfrc(i, j, 0) : 0.0;
     const HaloCell hu = halo_cell<2, 2>(uold, i0, j0, tx, ty), hv = halo_cell<2, 2>(vold, i0, j0, tx, ty), hHu = halo_cell<2, 2>(Huon, i0, j0, tx, ty),
                    hHv = halo_cell<2, 2>(Hvom, i0, j0, tx, ty), hW = halo_cell<2, 2>(W, i0, j0, tx, ty), hHz = halo_cell<1, 1>(Hz, i0, j0, tx, ty);
-    // column cursors of the own point and of this thread's halo cell (rh_tile.h)
-    const ColPtr cu = col_ptr(uold, i, j), cv = col_ptr(vold, i, j), cHu = col_ptr(Huon, i, j), cHv = col_ptr(Hvom, i, j), cHz = col_ptr(Hz, i, j),
-                 cW = col_ptr(W, i, j), cru = au ? col_ptr(ru, i, j, nrhs) : ColPtr{nullptr, 0}, crv = av ? col_ptr(rv, i, j, nrhs) : ColPtr{nullptr, 0};
-    const ColPtr qu = halo_ptr(uold, hu), qv = halo_ptr(vold, hv), qHu = halo_ptr(Huon, hHu), qHv = halo_ptr(Hvom, hHv), qW = halo_ptr(W, hW), qHz = halo_ptr(Hz, hHz);
+    // column cursors of the own point and of this thread's halo cell (rh_tile.h); every one can be dereferenced (points outside their
+    // array read a dummy), so the loads of a level are unconditional
+    const ColPtr cu = col_ptr_any(uold, i, j), cv = col_ptr_any(vold, i, j), cHu = col_ptr_any(Huon, i, j), cHv = col_ptr_any(Hvom, i, j), cHz = col_ptr_any(Hz, i, j),
+                 cW = col_ptr_any(W, i, j), cru = au ? col_ptr(ru, i, j, nrhs) : ColPtr{ru.p, 0}, crv = av ? col_ptr(rv, i, j, nrhs) : ColPtr{rv.p, 0};
+    const ColPtr qu = halo_ptr_any(uold, hu), qv = halo_ptr_any(vold, hv), qHu = halo_ptr_any(Huon, hHu), qHv = halo_ptr_any(Hvom, hHv), qW = halo_ptr_any(W, hW), qHz = halo_ptr_any(Hz, hHz);
     // vertical windows q(k-1), q(k), q(k+1), q(k+2) of the own point
-    double um1 = 0.0, u0 = col_ld(cu, 0), up1 = col_ld(cu, 1), up2 = (2 <= N) ? col_ld(cu, 2) : 0.0;
-    double vm1 = 0.0, v0 = col_ld(cv, 0), vp1 = col_ld(cv, 1), vp2 = (2 <= N) ? col_ld(cv, 2) : 0.0;
-    double Hu0 = col_ld(cHu, 0), Hv0 = col_ld(cHv, 0), hz = col_ld(cHz, 0), W1 = col_ld(cW, 1);
-    double uh = col_ld(qu, 0), vh = col_ld(qv, 0), Huh = col_ld(qHu, 0), Hvh = col_ld(qHv, 0), Wh = col_ld(qW, 1), hzh = col_ld(qHz, 0);
-    double rru = col_ld(cru, 0), rrv = col_ld(crv, 0);
+    double um1 = 0.0, u0 = col_ldu(cu, 0), up1 = col_ldu(cu, 1), up2 = col_ldu(cu, 2 <= N ? 2 : N);
+    double vm1 = 0.0, v0 = col_ldu(cv, 0), vp1 = col_ldu(cv, 1), vp2 = col_ldu(cv, 2 <= N ? 2 : N);
+    double Hu0 = col_ldu(cHu, 0), Hv0 = col_ldu(cHv, 0), hz = col_ldu(cHz, 0), W1 = col_ldu(cW, 1);
+    double uh = col_ldu(qu, 0), vh = col_ldu(qv, 0), Huh = col_ldu(qHu, 0), Hvh = col_ldu(qHv, 0), Wh = col_ldu(qW, 1), hzh = col_ldu(qHz, 0);
+    double rru = col_ldu(cru, 0), rrv = col_ldu(crv, 0);
     double FCu = 0.0, FCv = 0.0;
     for (int k = 0; k <= N; k++) {
         double *set = lds + (k & 1) * SET;
@@ -1106,14 +1107,16 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
         tile_put<2, 2>(sHu, tx, ty, Hu0, hHu, Huh); tile_put<2, 2>(sHv, tx, ty, Hv0, hHv, Hvh);
         tile_put<2, 2>(sW, tx, ty, W1, hW, Wh); tile_put<1, 1>(sHz, tx, ty, hz, hHz, hzh);
         // ---- prefetch level k+1
-        const bool more = k + 1 <= N;
-        const double u_n = (k + 3 <= N) ? col_ld(cu, k + 3) : 0.0, v_n = (k + 3 <= N) ? col_ld(cv, k + 3) : 0.0;
-        const double Hu0_n = more ? col_ld(cHu, k + 1) : 0.0, Hv0_n = more ? col_ld(cHv, k + 1) : 0.0, hz_n = more ? col_ld(cHz, k + 1) : 0.0;
-        const double W1_n = more ? col_ld(cW, k + 2) : 0.0;
-        const double uh_n = more ? col_ld(qu, k + 1) : 0.0, vh_n = more ? col_ld(qv, k + 1) : 0.0;
-        const double Huh_n = more ? col_ld(qHu, k + 1) : 0.0, Hvh_n = more ? col_ld(qHv, k + 1) : 0.0;
-        const double Wh_n = more ? col_ld(qW, k + 2) : 0.0, hzh_n = more ? col_ld(qHz, k + 1) : 0.0;
-        const double rru_n = more ? col_ld(cru, k + 1) : 0.0, rrv_n = more ? col_ld(crv, k + 1) : 0.0;
+        // levels past the top are clamped: what they load feeds only the iteration that does not exist (window values past N are
+        // never read: win_FCw)
+        const int k1 = k + 1 <= N ? k + 1 : N, k3 = k + 3 <= N ? k + 3 : N;
+        const double u_n = col_ldu(cu, k3), v_n = col_ldu(cv, k3);
+        const double Hu0_n = col_ldu(cHu, k1), Hv0_n = col_ldu(cHv, k1), hz_n = col_ldu(cHz, k1);
+        const double W1_n = col_ldu(cW, k1 + 1);
+        const double uh_n = col_ldu(qu, k1), vh_n = col_ldu(qv, k1);
+        const double Huh_n = col_ldu(qHu, k1), Hvh_n = col_ldu(qHv, k1);
+        const double Wh_n = col_ldu(qW, k1 + 1), hzh_n = col_ldu(qHz, k1);
+        const double rru_n = col_ldu(cru, k1), rrv_n = col_ldu(crv, k1);
         __syncthreads();
         const V2 tu{su, i0, j0}, tv{sv, i0, j0}, tHu{sHu, i0, j0}, tHv{sHv, i0, j0}, tW{sW, i0, j0};
         const V1 tHz{sHz, i0, j0};

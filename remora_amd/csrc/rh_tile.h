@@ -89,6 +89,22 @@ __device__ __forceinline__ ColPtr halo_ptr(const A4 &a, const HaloCell &h)
     return c;
 }
 __device__ __forceinline__ double col_ld(const ColPtr &c, int k) { return c.p ? c.p[(unsigned)k * c.sz] : 0.0; }
+// Cursors that can always be dereferenced: a point outside the array (or a thread without a halo cell) gets the array's first element
+// with stride 0, whose value the caller never uses.  A k-march can then issue every load of a level unconditionally -- no exec-mask
+// branch around each one (k_rhs_uv_tiled: 14 of them per level), and the loads of a level leave as one clause.
+__device__ __forceinline__ ColPtr col_ptr_any(const A4 &a, int i, int j, int n = 0)
+{
+    ColPtr c = col_ptr(a, i, j, n);
+    if (!c.p) { c.p = a.p; c.sz = 0; }
+    return c;
+}
+__device__ __forceinline__ ColPtr halo_ptr_any(const A4 &a, const HaloCell &h)
+{
+    ColPtr c = halo_ptr(a, h);
+    if (!c.p) { c.p = a.p; c.sz = 0; }
+    return c;
+}
+__device__ __forceinline__ double col_ldu(const ColPtr &c, int k) { return c.p[(unsigned)k * c.sz]; }
 __device__ __forceinline__ void col_st(const ColPtr &c, int k, double v) { c.p[(unsigned)k * c.sz] = v; }
 
 // The same for kernels whose threads only ever touch their own column: a view with the call syntax of A4 whose (i, j) arguments are
