@@ -61,3 +61,23 @@ def test_full_size_x_invariance_and_embedding(nx, ny, nz):
         a = v[..., ng0].cpu().numpy()
         assert np.array_equal(a, col[f][0]), f"{f}: 41-column run differs from the embedded columns"
     small.close()
+
+
+def test_bench_workload_fused_equals_leaf_by_leaf(monkeypatch):
+    """The bench's own workload (DoubleGyre physics, 2048 x 2048 x 50, BASELINE.json configs[3]) is not x-invariant, and the oracle
+    cannot run it in seconds.  Its size-independent check: two whole steps through the fused kernels the bench times must equal, BIT
+    FOR BIT and in every carried field, the same steps through the leaf-by-leaf path (`RH_UNFUSED=1`: one kernel per reference
+    function, stencils read straight from global memory, the three-kernel barotropic call, the batched BC passes) -- a second,
+    structurally different set of kernels that the small-size tests pin to the oracle (tests/test_gpu_parity.py)."""
+    from bench import bench_case
+    case = bench_case(2048, 2048, 50, 1, 1, "DoubleGyre")
+    fused = REMORA(case, device="cuda:0")
+    fused.InitData(); fused.Evolve(2); fused.sync()
+    monkeypatch.setenv("RH_UNFUSED", "1")
+    leaf = REMORA(case, device="cuda:0")
+    leaf.InitData(); leaf.Evolve(2); leaf.sync()
+    for f in FIELDS + ["cons_old", "xvel_old", "yvel_old", "rubar", "rvbar", "rzeta", "ru2d", "rv2d", "DU_avg2", "DV_avg1", "z_w", "rufrc", "rvfrc"]:
+        a = fused.view(f)[0]; b = leaf.view(f)[0]
+        assert torch.isfinite(a).all(), f
+        assert torch.equal(a, b), f"{f}: fused and leaf-by-leaf paths differ at full size"
+    fused.close(); leaf.close()
