@@ -37,7 +37,8 @@ ALGO_DOUBLES = {
     "rhs_t3": 10 + 3,              # sstore x3, t x3, Huon, Hvom, Hz, W -> t x3
     "rhs_uv_3d": 8 + 2,            # uold, vold, ru, rv, Huon, Hvom, W, Hz -> ru, rv          (coriolis folded in)
     "uv3dmix": 5 + 2,              # uold, vold, Hz, u, v -> u, v
-    "uv_corrector": 4 + 1,         # u, ru, Hz, Akv -> u     (AB3 + vert_visc_3d + vert_mean_3d; one launch per velocity)
+    "uv_corrector": 4 + 1,         # u, ru, Hz, Akv -> u     (AB3 + vert_visc_3d + vert_mean_3d; one launch per velocity); 5 + 2 when
+                                   # update_massflux_3d rides on the sweep (+ Huon read and written), see UV_CORRECTOR_MF below
     "vert_visc_3d": 3 + 1,         # phi, Hz, Akt -> phi
     "update_massflux_3d": 3 + 1,   # phi, Hphi, Hz -> Hphi (+ phi on boundary faces only)
     "massflux_omega_new": 6 + 3,   # u, v, Huon, Hvom, Hz, z_w -> Huon, Hvom, W   (advance_3d: update_massflux_3d x2 + omega in one sweep)
@@ -60,6 +61,7 @@ ALGO_DOUBLES = {
 #                                                                                                                   -> 16 + 8 + 5 = 29
 # nfast predictor and nfast corrector calls run fused per step: 30.5 on average (PMC: 32 doubles per column moved).
 K2D_DOUBLES = 30.5
+UV_CORRECTOR_MF = 5 + 2            # u, ru, Hz, Akv, Huon -> u, Huon   (the report then has a "massflux_rest" group and no "update_massflux_3d")
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_current.json")
 # kernel(s) behind each group in the rocprofv3 output (the traffic file's keys start with these)
 GROUP_KERNELS = {
@@ -294,6 +296,8 @@ def main():
             return K2D_DOUBLES * 8 * cols_per_gpu
         return ALGO_DOUBLES[g] * 8 * cells_per_gpu
 
+    if "massflux_rest" in rep:                             # the velocity corrector carried update_massflux_3d (valid non-wall faces)
+        ALGO_DOUBLES["uv_corrector"] = UV_CORRECTOR_MF
     # k2d_fused: one CALL of the barotropic kernel is two launches (interior, rim) when the exchange runs under it; price per call
     k2d_calls = 2 * rem.nfast * nprof
     if "k2d_fused" in rep and rep["k2d_fused"]["calls"] > k2d_calls:

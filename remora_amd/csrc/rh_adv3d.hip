@@ -331,6 +331,8 @@ k_column_solver(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm
     if (act)
         for (int k = 0; k <= N; k++) { double x = sDC[k * 64]; x -= DCm; x *= m; phi(i, j, k) = x; }
 }
+// what the velocity corrector needs to carry update_massflux_3d for its column as well (on = 0: not asked for)
+struct MfTail { int on, dlox, dhix, dloy, dhiy, perx, pery; A4 Hphi, phibar, Davg2; };
 // ---- the same solver with NO second read of its operands, for columns of up to VV_NZMAX levels.  The elimination coefficients
 // CF(k), DC(k) and the face-averaged AK(k) stay in REGISTERS (the loops over k are fully unrolled, so every index is a compile-time
 // constant; one wavefront per SIMD owns the whole 512-entry register file), the field the solve starts from and Hzk(k) are parked
@@ -342,7 +344,8 @@ k_column_solver(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm
 // the depths of the pinned cases and of the roofline configuration; any other depth takes k_column_solver.
 template <int IO, int JO, int FULL, int D, int NZ>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm, A4 pn, A4 msk, int /*N*/, double dt, double cab)
+k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm, A4 pn, A4 msk, int /*N*/, double dt, double cab,
+                    MfTail mf)
 {
     constexpr int N = NZ - 1, VV_NZMAX = NZ;
     extern __shared__ double vv_lds[];
@@ -433,6 +436,13 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
         }
     }
     if (!FULL) return;
+    // the old mass flux of the fused update_massflux_3d tail is requested here, while the depth mean is being summed
+    constexpr int MD = NZ > 50 ? 12 : 20;
+    double hq[MD];
+    if (mf.on) {
+#pragma unroll
+        for (int u = 0; u < MD; u++) hq[u] = mf.Hphi(ip, j, u < N ? u : N);
+    }
     // ---- vert_mean_3d: ascending sums in the reference's order (:22-34), then the correction (:36-46)
     double CF = sH[0], DCm = sX[0] * CF;
     for (int k = 1; k <= N; k++) { const double Hzf = sH[k * 64]; CF += Hzf; DCm += sX[k * 64] * Hzf; }
@@ -440,8 +450,40 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
     const double cff1 = 1.0 / (CF * (on));
     DCm = (DCm * (on) - Davg1(ip, j, 0)) * cff1;
     const double m = msk(ip, j, 0);
-    if (act)
-        for (int k = 0; k <= N; k++) { double x = sX[k * 64]; x -= DCm; x *= m; phi(i, j, k) = x; }
+    if (!mf.on) {
+        if (act)
+            for (int k = 0; k <= N; k++) { double x = sX[k * 64]; x -= DCm; x *= m; phi(i, j, k) = x; }
+        return;
+    }
+    // ---- update_massflux_3d (REMORA_update_massflux_3d.cpp:24-122) for this column while its final velocity and its layer thickness
+    // are still in LDS: Hphi = 1/2 (Hphi + phi DC) with its depth integral replaced by Davg2, phibar.  Same expressions and the same
+    // ascending sums as k_massflux_lds; DC(k) = (0.5 on) (Hz + Hz') is rebuilt from the parked Hzk = 0.5 (Hz' + Hz) (the factor 2 is
+    // exact).  Columns on a wall face are left out: the reference corrects their velocity after the physical BCs have been applied
+    // to it (advance_3d.cpp:154-155, then :87-101 of update_massflux_3d), so they wait for the strips pass that follows physbc.
+    const bool edge = (ip == mf.dlox - JO && !mf.perx) || (ip == mf.dhix + 1 && !mf.perx) || (j == mf.dloy - IO && !mf.pery) || (j == mf.dhiy + 1 && !mf.pery);
+    const bool mfa = act && !edge;
+    const double hon = 0.5 * on;
+    double DCs = 0.0, FCm = 0.0;
+#pragma clang loop unroll(full)
+    for (int k = 0; k < VV_NZMAX; k++) {
+        double x = sX[k * 64]; x -= DCm; x *= m;
+        if (act) phi(i, j, k) = x;
+        const double DCk = hon * (2.0 * sH[k * 64]);
+        DCs += DCk;
+        const double hp = 0.5 * (hq[k % MD] + x * DCk);
+        FCm += hp;
+        sX[k * 64] = hp;
+        hq[k % MD] = mf.Hphi(ip, j, k + MD < N ? k + MD : N);
+    }
+    const double DCi = 1.0 / DCs;
+    const double a1 = Davg1(ip, j, 0);
+    FCm = DCi * (FCm - mf.Davg2(ip, j, 0));
+    if (mfa) {
+#pragma clang loop unroll(full)
+        for (int k = 0; k < VV_NZMAX; k++) mf.Hphi(i, j, k) = sX[k * 64] - (hon * (2.0 * sH[k * 64])) * FCm;
+        const double pb = DCi * a1;
+        mf.phibar(i, j, 0, 0) = pb; mf.phibar(i, j, 0, 1) = pb;
+    }
 }
 static inline bool vv_reg_depth(int nz) { return nz == 13 || nz == 16 || nz == 50 || nz == 64; }
 #define VV_D_T 16      // ring depth, tracers (3 loads per level)
@@ -467,12 +509,13 @@ extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_
         const dim3 grid((phi_bx.hi[0] - phi_bx.lo[0] + 64) / 64, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);
         const dim3 gridu((phi_bx.hi[0] - phi_bx.lo[0] + 63) / 63, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);     // u waves overlap by one column
         const A4 z = mkA(phi);                           // unused operands of the FULL form
+        MfTail mfz; memset(&mfz, 0, sizeof mfz);
         const size_t lds_reg = sizeof(double) * 2 * (size_t)(N + 1) * 64;
         if (vv_reg_depth(N + 1) && !c->noregsolve) {     // a depth the register form is built for: no operand is read twice
 #define RH_VVR(NZ) do { \
-            if (ioff) k_column_solver_reg<1, 0, 0, VVD<NZ>::U, NZ><<<gridu, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); \
-            else if (joff) k_column_solver_reg<0, 1, 0, VVD<NZ>::V, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); \
-            else k_column_solver_reg<0, 0, 0, VVD<NZ>::T, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0); } while (0)
+            if (ioff) k_column_solver_reg<1, 0, 0, VVD<NZ>::U, NZ><<<gridu, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0, mfz); \
+            else if (joff) k_column_solver_reg<0, 1, 0, VVD<NZ>::V, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0, mfz); \
+            else k_column_solver_reg<0, 0, 0, VVD<NZ>::T, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0, mfz); } while (0)
             switch (N + 1) { case 13: RH_VVR(13); break; case 16: RH_VVR(16); break; case 64: RH_VVR(64); break; default: RH_VVR(50); break; }
 #undef RH_VVR
         }
@@ -507,10 +550,24 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     const dim3 gx((xbx.hi[0] - xbx.lo[0] + 63) / 63, xbx.hi[1] - xbx.lo[1] + 1, 1), gy((ybx.hi[0] - ybx.lo[0] + 64) / 64, ybx.hi[1] - ybx.lo[1] + 1, 1);
     const bool reg = vv_reg_depth(N + 1) && !c->noregsolve;
     const size_t lds_reg = sizeof(double) * 2 * (size_t)(N + 1) * 64;
+    // update_massflux_3d rides on the same sweep (the column's final velocity and thickness are in LDS when the corrector ends):
+    // *applied = 2 tells the caller to run update_massflux_3d only on what this launch leaves out (ghost faces, wall faces)
+    MfTail mfu, mfv; memset(&mfu, 0, sizeof mfu); memset(&mfv, 0, sizeof mfv);
+    const bool mf = reg && !c->no_mffuse;
+    if (mf) {
+        RH_NEED(s->Huon, xbx); RH_NEED(s->Hvom, ybx); RH_NEED(s->ubar, bx_slab(xbx, 2, 0)); RH_NEED(s->vbar, bx_slab(ybx, 2, 0));
+        RH_NEED(s->DU_avg2, bx_slab(xbx, 2, 0)); RH_NEED(s->DV_avg2, bx_slab(ybx, 2, 0));
+        if (s->ubar.ncomp < 2 || s->vbar.ncomp < 2) return rh_fail("launch_uv_corrector: ubar / vbar need 2 components");
+        mfu.on = mfv.on = 1;
+        mfu.dlox = mfv.dlox = c->dom.lo[0]; mfu.dhix = mfv.dhix = c->dom.hi[0]; mfu.dloy = mfv.dloy = c->dom.lo[1]; mfu.dhiy = mfv.dhiy = c->dom.hi[1];
+        mfu.perx = mfv.perx = c->prm.periodic[0]; mfu.pery = mfv.pery = c->prm.periodic[1];
+        mfu.Hphi = mkA(s->Huon); mfu.phibar = mkA(s->ubar); mfu.Davg2 = mkA(s->DU_avg2);
+        mfv.Hphi = mkA(s->Hvom); mfv.phibar = mkA(s->vbar); mfv.Davg2 = mkA(s->DV_avg2);
+    }
 #define RH_VVU(NZ) k_column_solver_reg<1, 0, 1, VVD<NZ>::U, NZ><<<gx, 64, lds_reg, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn), \
-        mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab)
+        mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab, mfu)
 #define RH_VVV(NZ) k_column_solver_reg<0, 1, 1, VVD<NZ>::V, NZ><<<gy, 64, lds_reg, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm), \
-        mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab)
+        mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab, mfv)
     { TScope t(c, "uv_corrector");
     if (reg) { switch (N + 1) { case 13: RH_VVU(13); break; case 16: RH_VVU(16); break; case 64: RH_VVU(64); break; default: RH_VVU(50); break; } }
     else k_column_solver<1, 0, 1, VV_D_U><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn),
@@ -521,7 +578,7 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     else k_column_solver<0, 1, 1, VV_D_V><<<gy, 64, lds_bytes, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm),
         mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab);
     RH_LAUNCH_CHECK();
-    *applied = 1;
+    *applied = mf ? 2 : 1;
     return 0;
 }
 
@@ -605,10 +662,11 @@ __global__ void k_massflux(B3 bx, int ioff, int joff, A4 phi, A4 phibar, A4 Hphi
 // operands of level k+D requested while level k is integrated (register ring, see k_column_solver).  Columns on a boundary face
 // (`edge`, :87-101) need the depth integral before their velocity is corrected: those few lanes redo their sums from memory.
 #define MF_D 10
+struct MfStrips { int n; int first[5]; int gx[4]; B3 b[4]; };        // n = 0: one box, the launch grid is its tiling
 template <int IO, int JO, int D>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_massflux_lds(B3 bx, A4 phi, A4 phibar, A4 Hphi, A4 Hz, A4 pmn, A4 Davg1, A4 Davg2, A4 msk,
-               int N, int dlox, int dhix, int dloy, int dhiy, int perx, int pery)
+k_massflux_lds(B3 bx0, A4 phi, A4 phibar, A4 Hphi, A4 Hz, A4 pmn, A4 Davg1, A4 Davg2, A4 msk,
+               int N, int dlox, int dhix, int dloy, int dhiy, int perx, int pery, MfStrips st)
 {
     extern __shared__ double mf_lds[];
     const int lane = threadIdx.x;
@@ -616,7 +674,15 @@ k_massflux_lds(B3 bx, A4 phi, A4 phibar, A4 Hphi, A4 Hz, A4 pmn, A4 Davg1, A4 Da
     // IO = 1: waves overlap by one column, lane 0 only carries Hz of the (i-1) neighbour of lane 1 into the shuffle; JO = 1: tiles in
     // 1 x 4 patches, so the row below is streamed by a wave of the same XCD at the same time (see k_column_solver)
     constexpr int SX = IO ? 63 : 64;
-    const RhTile rh_t_ = JO ? rh_tile_patch<1, 4>() : rh_tile();
+    B3 bx = bx0;
+    RhTile rh_t_;
+    if (st.n > 0) {                                                   // several thin boxes in one launch: block -> (strip, tile), in order
+        int r = (int)blockIdx.x, q = 0;
+        while (q + 1 < st.n && r >= st.first[q + 1]) q++;
+        r -= st.first[q];
+        bx = st.b[q];
+        rh_t_.x = r % st.gx[q]; rh_t_.y = r / st.gx[q];
+    } else rh_t_ = JO ? rh_tile_patch<1, 4>() : rh_tile();
     const int i = bx.lo0 - IO + rh_t_.x * SX + lane, j = bx.lo1 + rh_t_.y;
     const bool act = i <= bx.hi0 && !(IO && lane == 0);
     const int ic = i <= bx.hi0 ? i : bx.hi0;
@@ -676,10 +742,10 @@ k_massflux_lds(B3 bx, A4 phi, A4 phibar, A4 Hphi, A4 Hz, A4 pmn, A4 Davg1, A4 Da
         phibar(i, j, 0, 0) = pb; phibar(i, j, 0, 1) = pb;
     }
 }
-extern "C" int rh_update_massflux_3d(rh_ctx *c, rh_box bx, int ioff, int joff, rh_array4 phi, rh_array4 phibar, rh_array4 Hphi,
-                                     rh_array4 Hz, rh_array4 pm_or_pn, rh_array4 Dphi_avg1, rh_array4 Dphi_avg2, rh_array4 msk, int N)
+static int massflux_box(rh_ctx *c, const char *scope, rh_box bx, int ioff, int joff, rh_array4 phi, rh_array4 phibar, rh_array4 Hphi,
+                        rh_array4 Hz, rh_array4 pm_or_pn, rh_array4 Dphi_avg1, rh_array4 Dphi_avg2, rh_array4 msk, int N)
 {
-    TScope t(c, "update_massflux_3d");
+    TScope t(c, scope);
     if ((ioff | joff) != 1 || (ioff & joff)) return rh_fail("rh_update_massflux_3d: (ioff,joff) must be (1,0) or (0,1)");
     bx.lo[2] = 0; bx.hi[2] = N;
     rh_box bs = bx; bs.lo[0] -= ioff; bs.lo[1] -= joff;
@@ -692,8 +758,9 @@ extern "C" int rh_update_massflux_3d(rh_ctx *c, rh_box bx, int ioff, int joff, r
         RH_HIP(rh_lds_optin(k_massflux_lds<1, 0, MF_D>, lds_bytes)); RH_HIP(rh_lds_optin(k_massflux_lds<0, 1, MF_D>, lds_bytes));
         const int sx = ioff ? 63 : 64;                                 // u waves overlap by one column
         const dim3 grid((bx.hi[0] - bx.lo[0] + sx) / sx, bx.hi[1] - bx.lo[1] + 1, 1);
+        MfStrips st0; memset(&st0, 0, sizeof st0);
 #define RH_MF(IO, JO) k_massflux_lds<IO, JO, MF_D><<<grid, 64, lds_bytes, c->stream>>>(mkB(bx), mkA(phi), mkA(phibar), mkA(Hphi), mkA(Hz), mkA(pm_or_pn), \
-            mkA(Dphi_avg1), mkA(Dphi_avg2), mkA(msk), N, c->dom.lo[0], c->dom.hi[0], c->dom.lo[1], c->dom.hi[1], c->prm.periodic[0], c->prm.periodic[1])
+            mkA(Dphi_avg1), mkA(Dphi_avg2), mkA(msk), N, c->dom.lo[0], c->dom.hi[0], c->dom.lo[1], c->dom.hi[1], c->prm.periodic[0], c->prm.periodic[1], st0)
         if (ioff) RH_MF(1, 0); else RH_MF(0, 1);
 #undef RH_MF
     } else
@@ -702,6 +769,58 @@ extern "C" int rh_update_massflux_3d(rh_ctx *c, rh_box bx, int ioff, int joff, r
     RH_LAUNCH_CHECK(); return 0;
 }
 
+extern "C" int rh_update_massflux_3d(rh_ctx *c, rh_box bx, int ioff, int joff, rh_array4 phi, rh_array4 phibar, rh_array4 Hphi,
+                                     rh_array4 Hz, rh_array4 pm_or_pn, rh_array4 Dphi_avg1, rh_array4 Dphi_avg2, rh_array4 msk, int N)
+{ return massflux_box(c, "update_massflux_3d", bx, ioff, joff, phi, phibar, Hphi, Hz, pm_or_pn, Dphi_avg1, Dphi_avg2, msk, N); }
+// update_massflux_3d on what the velocity corrector's fused tail left out of `full` (advance_3d.cpp:213,218 run it on the cell box
+// grown by two, read as a face box): the ghost faces around the valid faces `done`, and the wall faces of a non-periodic side, whose
+// velocity the physical BCs have set in the meantime.  Up to four strips.
+int launch_massflux_rest(rh_ctx *c, rh_box full, rh_box done, int ioff, int joff, rh_array4 phi, rh_array4 phibar, rh_array4 Hphi,
+                         rh_array4 Hz, rh_array4 pm_or_pn, rh_array4 Dphi_avg1, rh_array4 Dphi_avg2, rh_array4 msk, int N)
+{
+    // wall faces (k_column_solver_reg: `edge`) sit on the first / last face line of the normal direction
+    if (ioff) { if (!c->prm.periodic[0]) { if (done.lo[0] == c->dom.lo[0]) done.lo[0] += 1; if (done.hi[0] == c->dom.hi[0] + 1) done.hi[0] -= 1; } }
+    else      { if (!c->prm.periodic[1]) { if (done.lo[1] == c->dom.lo[1]) done.lo[1] += 1; if (done.hi[1] == c->dom.hi[1] + 1) done.hi[1] -= 1; } }
+    rh_box q[4] = {full, full, full, full};
+    q[0].hi[1] = done.lo[1] - 1;                                                     // rows below
+    q[1].lo[1] = done.hi[1] + 1;                                                     // rows above
+    q[2].lo[1] = done.lo[1]; q[2].hi[1] = done.hi[1]; q[2].hi[0] = done.lo[0] - 1;   // columns left
+    q[3].lo[1] = done.lo[1]; q[3].hi[1] = done.hi[1]; q[3].lo[0] = done.hi[0] + 1;   // columns right
+    const size_t lds_bytes = sizeof(double) * 2 * (size_t)(N + 1) * 64;
+    if (c->unfused || lds_bytes > RH_LDS_MAX) {
+        for (const rh_box &r : q) {
+            if (r.lo[0] > r.hi[0] || r.lo[1] > r.hi[1]) continue;
+            RH_TRY(massflux_box(c, "massflux_rest", r, ioff, joff, phi, phibar, Hphi, Hz, pm_or_pn, Dphi_avg1, Dphi_avg2, msk, N));
+        }
+        return 0;
+    }
+    // the strips as ONE launch of the column kernel (each is a few rows or columns wide: as launches of their own they cost a column
+    // march's latency each)
+    TScope t(c, "massflux_rest");
+    MfStrips st; memset(&st, 0, sizeof st);
+    const int sx = ioff ? 63 : 64;
+    int total = 0;
+    for (rh_box r : q) {
+        if (r.lo[0] > r.hi[0] || r.lo[1] > r.hi[1]) continue;
+        r.lo[2] = 0; r.hi[2] = N;
+        rh_box bs = r; bs.lo[0] -= ioff; bs.lo[1] -= joff;
+        const rh_box b2 = bx_slab(r, 2, 0);
+        RH_NEED(phi, r); RH_NEED(Hphi, r); RH_NEED(Hz, bs); RH_NEED(pm_or_pn, bx_slab(bs, 2, 0));
+        RH_NEED(phibar, b2); RH_NEED(Dphi_avg1, b2); RH_NEED(Dphi_avg2, b2); RH_NEED(msk, b2);
+        const int gx = (r.hi[0] - r.lo[0] + sx) / sx, gy = r.hi[1] - r.lo[1] + 1;
+        st.b[st.n] = mkB(r); st.gx[st.n] = gx; st.first[st.n] = total; total += gx * gy; st.n++;
+    }
+    if (!st.n) return 0;
+    st.first[st.n] = total;
+    if (phibar.ncomp < 2) return rh_fail("launch_massflux_rest: phibar needs 2 components");
+    RH_HIP(rh_lds_optin(k_massflux_lds<1, 0, MF_D>, lds_bytes)); RH_HIP(rh_lds_optin(k_massflux_lds<0, 1, MF_D>, lds_bytes));
+#define RH_MFS(IO, JO) k_massflux_lds<IO, JO, MF_D><<<total, 64, lds_bytes, c->stream>>>(st.b[0], mkA(phi), mkA(phibar), mkA(Hphi), mkA(Hz), mkA(pm_or_pn), \
+        mkA(Dphi_avg1), mkA(Dphi_avg2), mkA(msk), N, c->dom.lo[0], c->dom.hi[0], c->dom.lo[1], c->dom.hi[1], c->prm.periodic[0], c->prm.periodic[1], st)
+    if (ioff) RH_MFS(1, 0); else RH_MFS(0, 1);
+#undef RH_MFS
+    RH_LAUNCH_CHECK();
+    return 0;
+}
 // ------------------------------------------------------------------------------------------------------------------
 // REMORA::rhs_t_3d, REMORA_rhs_t_3d.cpp:27-335: corrector tracer advection with the predictor field sstore, one tracer.
 // Horizontal fluxes (third-order upstream / fourth-order centred, flat-bathymetry sign quirk included), horizontal update,

@@ -160,6 +160,7 @@ struct rh_ctx {
     // interior tiles on the compute stream; it then runs on the side stream, under them
     struct { bool on = false; rh_array4 ubar, vbar, zeta, msku, mskv, mskr; int knew = 0; } pend2d;
     hipEvent_t ev2d_m = nullptr, ev2d_b = nullptr;
+    bool no_mffuse = false;                                    // RH_NO_MFFUSE=1: update_massflux_3d always as its own launches
     bool in_loop2d = false, no_split2d = false;                // RH_NO_SPLIT2D=1: never split k2d_fused into interior and rim launches
     bool async_on = false, async_pending = false, in_advance = false, no_async = false, async_rccl = false;
     hipStream_t last_comm_stream = nullptr; bool comm_used = false;
@@ -220,7 +221,9 @@ int  launch_massflux_omega(rh_ctx *c, rh_state *s, rh_box gbx1, int N, int *appl
 int  launch_vmix(rh_ctx *c, rh_state *s);
 int  launch_set_zeta(rh_ctx *c, rh_state *s);
 int  launch_uv_ab3(rh_ctx *c, rh_state *s, int istep);
-int  launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied);   // fused: AB3 + vert_visc_3d + vert_mean_3d for u, v
+int  launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied);   // fused: AB3 + vert_visc_3d + vert_mean_3d for u, v (*applied = 2: + update_massflux_3d on the valid non-wall faces)
+int  launch_massflux_rest(rh_ctx *c, rh_box full, rh_box done, int ioff, int joff, rh_array4 phi, rh_array4 phibar, rh_array4 Hphi,
+                          rh_array4 Hz, rh_array4 pm_or_pn, rh_array4 Dphi_avg1, rh_array4 Dphi_avg2, rh_array4 msk, int N);
 int  launch_mask_cons(rh_ctx *c, rh_state *s);
 int  launch_rho_eos_P(rh_ctx *c, rh_state *s, rh_box bx, rh_box pbx);
 int  launch_prestep_uv2(rh_ctx *c, rh_state *s, rh_box bx, rh_box dead_u, rh_box dead_v, int iic, int ntfirst, int nrhs, int N, double dt);

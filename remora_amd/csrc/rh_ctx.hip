@@ -425,6 +425,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     c->gls_libm_pow = getenv("RH_GLS_LIBM_POW") && atoi(getenv("RH_GLS_LIBM_POW")) != 0;
     c->no_async = getenv("RH_NO_ASYNC") && atoi(getenv("RH_NO_ASYNC")) != 0;
     c->async_rccl = getenv("RH_ASYNC_RCCL") && atoi(getenv("RH_ASYNC_RCCL")) != 0;
+    c->no_mffuse = getenv("RH_NO_MFFUSE") && atoi(getenv("RH_NO_MFFUSE")) != 0;
     c->no_split2d = getenv("RH_NO_SPLIT2D") && atoi(getenv("RH_NO_SPLIT2D")) != 0;
     c->no_bc2d = getenv("RH_NO_BC2D") && atoi(getenv("RH_NO_BC2D")) != 0;
     c->poison = getenv("RH_POISON") && atoi(getenv("RH_POISON")) != 0;

@@ -189,8 +189,13 @@ static int advance_3d(rh_ctx *c, rh_state *s, int istep)
         RH_TRY(halo_physbc(c, mfv(c, s->yvel_new, 0, 1, 0), s->mskv, 0, 1, RH_BCV_YVEL, 0, &s->yvel_old));
         RH_TRY(bcs.end());
     }
-    RH_TRY(rh_update_massflux_3d(c, gbx2, 1, 0, s->xvel_new, s->ubar, s->Huon, s->Hz, s->pn, s->DU_avg1, s->DU_avg2, s->msku, N));   // :213
-    RH_TRY(rh_update_massflux_3d(c, gbx2, 0, 1, s->yvel_new, s->vbar, s->Hvom, s->Hz, s->pm, s->DV_avg1, s->DV_avg2, s->mskv, N));   // :218
+    if (fused_uv == 2) {                                   // the corrector's sweep did the valid faces; ghost and wall faces remain
+        RH_TRY(launch_massflux_rest(c, gbx2, xbx, 1, 0, s->xvel_new, s->ubar, s->Huon, s->Hz, s->pn, s->DU_avg1, s->DU_avg2, s->msku, N));   // :213
+        RH_TRY(launch_massflux_rest(c, gbx2, ybx, 0, 1, s->yvel_new, s->vbar, s->Hvom, s->Hz, s->pm, s->DV_avg1, s->DV_avg2, s->mskv, N));   // :218
+    } else {
+        RH_TRY(rh_update_massflux_3d(c, gbx2, 1, 0, s->xvel_new, s->ubar, s->Huon, s->Hz, s->pn, s->DU_avg1, s->DU_avg2, s->msku, N));   // :213
+        RH_TRY(rh_update_massflux_3d(c, gbx2, 0, 1, s->yvel_new, s->vbar, s->Hvom, s->Hz, s->pm, s->DV_avg1, s->DV_avg2, s->mskv, N));   // :218
+    }
     RH_TRY(zero_outside(c, c->W, gbx1));                                                           // :230-231 (omega overwrites gbx1)
     RH_TRY(rh_omega(c, gbx1, c->W, s->Huon, s->Hvom, s->z_w, s->h, N));                            // :272-293
     if (c->prm.vmix_mode == RH_VMIX_GLS) RH_TRY(rh_gls_corrector(c, s, c->W, istep % 2, 1 - istep % 2));   // :296-303

@@ -1,7 +1,7 @@
 """The A/B switches INTEGRATION.md advertises (read by rh_create) and the bench workload's physics at a many-tile size.
 
 * RH_NOFUSE2D=1 (three-kernel barotropic call), RH_NOREGSOLVE=1 (LDS-ring column solver at every depth), RH_NO_ASYNC=1 (no side
-  stream), RH_NO_BC2D=1 (ghost cells of the barotropic step through the batched BC passes instead of the rim blocks of k2d_fused) must give the same bits as the default path: each is checked against the oracle on the bit-exact cases.
+  stream), RH_NO_BC2D=1 (ghost cells of the barotropic step through the batched BC passes instead of the rim blocks of k2d_fused) and RH_NO_MFFUSE=1 (update_massflux_3d as its own launches instead of on the velocity corrector's sweep) must give the same bits as the default path: each is checked against the oracle on the bit-exact cases.
 * RH_POISON=1 fills the library's work arrays with NaN at the top of every step: a kernel that read scratch it had not written
   in the same step would produce NaN (and differ from the oracle).
 * DoubleGyre physics, the bench workload's depth (50 levels) and boundary conditions (all walls), on 512 x 512 columns = 8 x 64
@@ -40,7 +40,7 @@ def _phases(cfg, nsteps, what):
     rem.close(); orc.close()
 
 
-@pytest.mark.parametrize("switch", ["RH_NOFUSE2D", "RH_NOREGSOLVE", "RH_POISON", "RH_NO_ASYNC", "RH_NO_BC2D"])
+@pytest.mark.parametrize("switch", ["RH_NOFUSE2D", "RH_NOREGSOLVE", "RH_POISON", "RH_NO_ASYNC", "RH_NO_BC2D", "RH_NO_MFFUSE"])
 @pytest.mark.parametrize("case", ["Seamount", "DoubleGyre"])
 def test_switch_keeps_the_bits(switch, case, monkeypatch):
     monkeypatch.setenv(switch, "1")
