@@ -781,6 +781,8 @@ int launch_massflux_rest(rh_ctx *c, rh_box full, rh_box done, int ioff, int joff
     // wall faces (k_column_solver_reg: `edge`) sit on the first / last face line of the normal direction
     if (ioff) { if (!c->prm.periodic[0]) { if (done.lo[0] == c->dom.lo[0]) done.lo[0] += 1; if (done.hi[0] == c->dom.hi[0] + 1) done.hi[0] -= 1; } }
     else      { if (!c->prm.periodic[1]) { if (done.lo[1] == c->dom.lo[1]) done.lo[1] += 1; if (done.hi[1] == c->dom.hi[1] + 1) done.hi[1] -= 1; } }
+    if (done.lo[0] > done.hi[0] || done.lo[1] > done.hi[1])                          // every face of this box is a wall face: nothing was done
+        return massflux_box(c, "massflux_rest", full, ioff, joff, phi, phibar, Hphi, Hz, pm_or_pn, Dphi_avg1, Dphi_avg2, msk, N);
     rh_box q[4] = {full, full, full, full};
     q[0].hi[1] = done.lo[1] - 1;                                                     // rows below
     q[1].lo[1] = done.hi[1] + 1;                                                     // rows above
