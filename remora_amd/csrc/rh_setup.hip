@@ -747,22 +747,23 @@ int launch_rho_eos_P(rh_ctx *c, rh_state *s, rh_box bx, rh_box pbx)
     return 0;
 }
 
-__global__ void __launch_bounds__(RT_BX * RT_BY)
+#define PG_BY 16        // rows per block: halo rows are (PG_BY + 2 HY) / PG_BY of the tile reads
+__global__ void __launch_bounds__(RT_BX * PG_BY)
 k_prsgrd_uv_tiled(B3 ub, B3 vb, B3 un, A4 ru, A4 rv, A4 pn, A4 pm, A4 rho, A4 P, A4 Hz, A4 z_r, A4 msku, A4 mskv, int nrhs, double HalfGRho)
 {
-    typedef Tile<2, 2> T2; typedef Tile<1, 1> T1;
+    typedef Tile<2, 2, PG_BY> T2; typedef Tile<1, 1, PG_BY> T1;
     constexpr int SET = 2 * T2::SIZE + 2 * T1::SIZE;
     __shared__ double lds[2 * SET];
     const int tx = threadIdx.x, ty = threadIdx.y;
     const RhTile rh_t_ = rh_tile();
-    const int i0 = un.lo0 + rh_t_.x * RT_BX, j0 = un.lo1 + rh_t_.y * RT_BY;
+    const int i0 = un.lo0 + rh_t_.x * RT_BX, j0 = un.lo1 + rh_t_.y * PG_BY;
     const int i = i0 + tx, j = j0 + ty;
     const bool au = inb2(ub, i, j), av = inb2(vb, i, j);
     double on_u = 0.0, om_v = 0.0, mu1 = 0.0, mu0 = 0.0, mup = 0.0, mv1 = 0.0, mv0 = 0.0, mvp = 0.0;
     if (au) { on_u = 2.0 / (pn(i - 1, j, 0) + pn(i, j, 0)); mu1 = msku(i - 1, j, 0); mu0 = msku(i, j, 0); mup = msku(i + 1, j, 0); }
     if (av) { om_v = 2.0 / (pm(i, j - 1, 0) + pm(i, j, 0)); mv1 = mskv(i, j - 1, 0); mv0 = mskv(i, j, 0); mvp = mskv(i, j + 1, 0); }
-    const HaloCell hr = halo_cell<2, 2>(rho, i0, j0, tx, ty), hz = halo_cell<2, 2>(z_r, i0, j0, tx, ty),
-                   hp = halo_cell<1, 1>(P, i0, j0, tx, ty), hh = halo_cell<1, 1>(Hz, i0, j0, tx, ty);
+    const HaloCell hr = halo_cell<2, 2, PG_BY>(rho, i0, j0, tx, ty), hz = halo_cell<2, 2, PG_BY>(z_r, i0, j0, tx, ty),
+                   hp = halo_cell<1, 1, PG_BY>(P, i0, j0, tx, ty), hh = halo_cell<1, 1, PG_BY>(Hz, i0, j0, tx, ty);
     const int k0 = un.lo2, k1 = un.hi2;
     double r0 = ld_in(rho, i, j, k0), z0 = ld_in(z_r, i, j, k0), p0 = ld_in(P, i, j, k0), h0 = ld_in(Hz, i, j, k0);
     double rh = halo_ld(rho, hr, k0), zh = halo_ld(z_r, hz, k0), ph = halo_ld(P, hp, k0), hhv = halo_ld(Hz, hh, k0);
@@ -776,7 +777,7 @@ k_prsgrd_uv_tiled(B3 ub, B3 vb, B3 un, A4 ru, A4 rv, A4 pn, A4 pm, A4 rho, A4 P,
             rh = halo_ld(rho, hr, k + 1); zh = halo_ld(z_r, hz, k + 1); ph = halo_ld(P, hp, k + 1); hhv = halo_ld(Hz, hh, k + 1);
         }
         __syncthreads();
-        const TView<2, 2> vr{sr, i0, j0}, vz{sz, i0, j0}; const TView<1, 1> vp{sp, i0, j0}, vh{sh, i0, j0};
+        const TView<2, 2, PG_BY> vr{sr, i0, j0}, vz{sz, i0, j0}; const TView<1, 1, PG_BY> vp{sp, i0, j0}, vh{sh, i0, j0};
         if (au) ru(i, j, k, nrhs) = prsgrd_point(vr, vz, vp, vh, i, j, k, 1, 0, mu1, mu0, mup, on_u, HalfGRho);
         if (av) rv(i, j, k, nrhs) = prsgrd_point(vr, vz, vp, vh, i, j, k, 0, 1, mv1, mv0, mvp, om_v, HalfGRho);
     }
@@ -806,7 +807,8 @@ extern "C" int rh_prsgrd(rh_ctx *c, rh_box phi_bx, rh_box utbx, rh_box vtbx, rh_
         k_prsgrd_uv<<<grid3(un), rh_block(), 0, c->stream>>>(mkB(utbx), mkB(vtbx), mkB(un), mkA(ru), mkA(rv), mkA(pn), mkA(pm), mkA(rho),
             mkA(P), mkA(Hz), mkA(z_r), mkA(msku), mkA(mskv), nrhs, HalfGRho);
     else {
-        k_prsgrd_uv_tiled<<<rt_grid(un), rt_block(), 0, c->stream>>>(mkB(utbx), mkB(vtbx), mkB(un), mkA(ru), mkA(rv), mkA(pn), mkA(pm), mkA(rho),
+        const dim3 pg((un.hi[0] - un.lo[0] + RT_BX) / RT_BX, (un.hi[1] - un.lo[1] + PG_BY) / PG_BY, 1);
+        k_prsgrd_uv_tiled<<<pg, dim3(RT_BX, PG_BY, 1), 0, c->stream>>>(mkB(utbx), mkB(vtbx), mkB(un), mkA(ru), mkA(rv), mkA(pn), mkA(pm), mkA(rho),
             mkA(P), mkA(Hz), mkA(z_r), mkA(msku), mkA(mskv), nrhs, HalfGRho);
     }
     RH_LAUNCH_CHECK(); return 0;

@@ -47,16 +47,16 @@ struct TView {
 // for level k+1 is fetched into a register while level k is being computed, and put() writes own value + halo value into LDS
 // at the top of the next iteration -- no load sits between the LDS stores and the barrier.  One halo cell per thread at most.
 struct HaloCell { int lds; unsigned g; };    // LDS offset inside the tile (-1: none) and element offset inside one k-plane of the array
-template <int HX, int HY>
+template <int HX, int HY, int BY = RT_BY>
 __device__ __forceinline__ HaloCell halo_cell(const A4 &a, int i0, int j0, int tx, int ty)
 {
-    typedef Tile<HX, HY> T;
-    static_assert(T::NHALO <= RT_BX * RT_BY, "one halo cell per thread");
+    typedef Tile<HX, HY, BY> T;
+    static_assert(T::NHALO <= RT_BX * BY, "one halo cell per thread");
     HaloCell h; h.lds = -1; h.g = 0;
     const int t = ty * RT_BX + tx;
     if (t < T::NHALO) {
         int x, y;
-        if (t < T::NROWCELLS) { const int r = t / T::PX; x = t - r * T::PX; y = r < HY ? r : RT_BY + r; }
+        if (t < T::NROWCELLS) { const int r = t / T::PX; x = t - r * T::PX; y = r < HY ? r : BY + r; }
         else { constexpr int W2 = 2 * HX > 0 ? 2 * HX : 1; const int u = t - T::NROWCELLS; const int r = u / W2; const int xx = u - r * W2; y = HY + r; x = xx < HX ? xx : RT_BX + xx; }
         const int gi = i0 - HX + x, gj = j0 - HY + y;
         if (gi >= a.lo0 && gi <= a.hi0 && gj >= a.lo1 && gj <= a.hi1) { h.lds = y * T::PX + x; h.g = (unsigned)(gi - a.lo0) + (unsigned)(gj - a.lo1) * a.sy; }
