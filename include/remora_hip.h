@@ -284,6 +284,11 @@ typedef struct rh_init_params {
 int  rh_init_state(rh_ctx *ctx, rh_state *s, const rh_init_params *ip);
 /* plotfile variables of IO/REMORA_Plotfile.cpp:185-235 on the valid box: temp, salt, [scalar], cell-centred u, v, w
  * (device output buffer, FAB order) */
+/* REMORA::update_mskp (Initialization/REMORA_make_new_level.cpp:617-655) followed by the periodic ghost fill of mskr / msku / mskv /
+ * mskp (REMORA::init_masks_from_netcdf, Initialization/REMORA_init_from_netcdf.cpp:408-412): what the reference does once the
+ * land / sea masks have been read.  The caller has written mskr, msku, mskv of the state (1 = water, 0 = land) over their valid
+ * boxes and, on non-periodic sides, their ghost cells; rh_params.masks_all_one must be 0 for the step to read them. */
+int  rh_update_mskp(rh_ctx *ctx, rh_state *s);
 int  rh_plot_vars(rh_ctx *ctx, rh_state *s, int with_scalar, double *out_device);
 
 /* ---- AMReX-native plotfile output (outside the hot path; so that amrex_fcompare / yt / VisIt read the results) ----

@@ -159,6 +159,14 @@ void REMORA::advance_3d_ml (int lev, Real /*dt_lev*/)
     RH_CALL(rh_advance_3d_ml(m_rh[lev], &s, istep[lev]));
 }
 
+// Initialization/REMORA_make_new_level.cpp:617-655.  rh_update_mskp also refills the periodic ghost cells of the four masks, which
+// init_masks_from_netcdf does right after this call (REMORA_init_from_netcdf.cpp:408-412): those FillBoundary calls become no-ops.
+void REMORA::update_mskp (int lev)
+{
+    rh_state s = rh_bind_state(lev);
+    RH_CALL(rh_update_mskp(m_rh[lev], &s));
+}
+
 // ---------------------------------------------------------------------------------------------------------------- leaves
 // REMORA_vert_visc_3d.cpp:10-107: the six scratch arrays (Hzk, AK, BC, DC, FC, CF) are not needed, the solve lives in registers / LDS
 void REMORA::vert_visc_3d (const Box& phi_bx, const int ioff, const int joff,

@@ -881,6 +881,33 @@ void o_advance(OState *s)                                                      /
     o_end_step(s);
 }
 
+/* REMORA::update_mskp, Initialization/REMORA_make_new_level.cpp:617-655: the vorticity-point mask from the four rho-point masks
+ * around the node, on the cell box grown by one: 1 with all four wet or exactly one dry, 2 with two dry cells side by side (a
+ * straight coast), 0 otherwise (two dry cells across a diagonal, three or four dry) */
+void o_update_mskp(OState *s)
+{
+    Fab mr=F(mskr), mp=F(mskp);
+    for(int j=s->bx.lo[1]-1;j<=s->bx.hi[1]+1;j++) for(int i=s->bx.lo[0]-1;i<=s->bx.hi[0]+1;i++){
+        int a=V(mr,i-1,j,0)>0.5, b=V(mr,i,j,0)>0.5, c=V(mr,i-1,j-1,0)>0.5, d=V(mr,i,j-1,0)>0.5;   /* :631 order of the tests */
+        int a0=V(mr,i-1,j,0)<0.5, b0=V(mr,i,j,0)<0.5, c0=V(mr,i-1,j-1,0)<0.5, d0=V(mr,i,j-1,0)<0.5;
+        double v;
+        if(a&&b&&c&&d) v=1.0;
+        else if(a0&&b&&c&&d) v=1.0;
+        else if(a&&b0&&c&&d) v=1.0;
+        else if(a&&b&&c0&&d) v=1.0;
+        else if(a&&b&&c&&d0) v=1.0;
+        else if(a&&b0&&c&&d0) v=2.0;
+        else if(a0&&b&&c0&&d) v=2.0;
+        else if(a&&b&&c0&&d0) v=2.0;
+        else if(a0&&b0&&c&&d) v=2.0;
+        else v=0.0;
+        V(mp,i,j,0)=v;
+    }
+    /* Initialization/REMORA_init_from_netcdf.cpp:408-412: ghost cells of the four masks across periodic sides */
+    o_fill_boundary(&s->geom,&s->mskr,0,1); o_fill_boundary(&s->geom,&s->msku,0,1);
+    o_fill_boundary(&s->geom,&s->mskv,0,1); o_fill_boundary(&s->geom,&s->mskp,0,1);
+}
+
 int o_nfast(const OState *s){ return s->nfast; }
 int o_istep(const OState *s){ return s->istep; }
 

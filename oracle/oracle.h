@@ -136,6 +136,7 @@ void    o_advance_2d_onestep(OState*,int my_iif);
 void    o_advance_3d_ml(OState*);
 void    o_begin_step(OState*);                    /* swap old/new, time bookkeeping */
 void    o_end_step(OState*);
+void    o_update_mskp(OState*);                   /* mskp from mskr, make_new_level.cpp:617-655 */
 int     o_nfast(const OState*);
 int     o_istep(const OState*);
 /* field access by name: returns pointer + box + ncomp (0 on unknown name) */

@@ -62,7 +62,7 @@ def lib():
         _lib = C.CDLL(_LIB)
         _lib.o_create.restype = C.c_void_p
         _lib.o_create.argtypes = [C.POINTER(Params)]
-        for f in ("o_destroy", "o_advance", "o_setup_step", "o_advance_3d_ml", "o_begin_step", "o_end_step"):
+        for f in ("o_destroy", "o_advance", "o_setup_step", "o_advance_3d_ml", "o_begin_step", "o_end_step", "o_update_mskp"):
             getattr(_lib, f).argtypes = [C.c_void_p]
             getattr(_lib, f).restype = None
         _lib.o_advance_2d_onestep.argtypes = [C.c_void_p, C.c_int]
@@ -146,6 +146,7 @@ class Oracle:
     def setup_step(self): lib().o_setup_step(self.h)
     def advance_2d_onestep(self, iif): lib().o_advance_2d_onestep(self.h, iif)
     def advance_3d_ml(self): lib().o_advance_3d_ml(self.h)
+    def update_mskp(self): lib().o_update_mskp(self.h)
 
     def field(self, name):
         """numpy view [comp, k, j, i] on the oracle's grown array, plus (lo, hi)."""

@@ -500,6 +500,33 @@ extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
     return 0;
 }
 
+// REMORA::update_mskp, Initialization/REMORA_make_new_level.cpp:617-655: the vorticity-point mask of a node from the four rho-point
+// masks around it (1: all wet or one dry; 2: two dry cells side by side, a straight coast; 0: anything else), on the cell box grown
+// by one; then the ghost cells of the four masks as REMORA::init_masks_from_netcdf leaves them (init_from_netcdf.cpp:408-412).
+__global__ void k_update_mskp(B3 b, A4 mskr, A4 mskp)
+{
+    RH_IJ(b); if (!inb2(b, i, j)) return;
+    const bool a = mskr(i - 1, j, 0) > 0.5, bb = mskr(i, j, 0) > 0.5, cc = mskr(i - 1, j - 1, 0) > 0.5, d = mskr(i, j - 1, 0) > 0.5;
+    const bool a0 = mskr(i - 1, j, 0) < 0.5, b0 = mskr(i, j, 0) < 0.5, c0 = mskr(i - 1, j - 1, 0) < 0.5, d0 = mskr(i, j - 1, 0) < 0.5;
+    double v = 0.0;
+    if (a && bb && cc && d) v = 1.0;
+    else if ((a0 && bb && cc && d) || (a && b0 && cc && d) || (a && bb && c0 && d) || (a && bb && cc && d0)) v = 1.0;
+    else if ((a && b0 && cc && d0) || (a0 && bb && c0 && d) || (a && bb && c0 && d0) || (a0 && b0 && cc && d)) v = 2.0;
+    mskp(i, j, 0) = v;
+}
+extern "C" int rh_update_mskp(rh_ctx *c, rh_state *s)
+{
+    const rh_box b = bx_grow(bx_slab(c->bx, 2, 0), 1, 1, 0);
+    RH_NEED(s->mskp, b); RH_NEED(s->mskr, bx_grow(b, 1, 1, 0));
+    k_update_mskp<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(s->mskr), mkA(s->mskp));
+    RH_LAUNCH_CHECK();
+    RH_TRY(halo_fill_boundary(c, mfv(c, s->mskr, 0, 0, 0), 0, 1));
+    RH_TRY(halo_fill_boundary(c, mfv(c, s->msku, 1, 0, 0), 0, 1));
+    RH_TRY(halo_fill_boundary(c, mfv(c, s->mskv, 0, 1, 0), 0, 1));
+    RH_TRY(halo_fill_boundary(c, mfv(c, s->mskp, 1, 1, 0), 0, 1));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // plotfile variables, IO/REMORA_Plotfile.cpp:185-235: temp, salt, [scalar], cell-centred averages of the face velocities
 __global__ void k_plot(B3 b, A4 cons, A4 u, A4 v, A4 w, double *__restrict__ out, int with_scalar)

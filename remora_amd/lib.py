@@ -158,6 +158,7 @@ SIGNATURES = {
     "rh_swap_old_new": (None, [_SP]),
     "rh_init_state": (C.c_int, [_P, _SP, C.POINTER(InitParams)]),
     "rh_plot_vars": (C.c_int, [_P, _SP, C.c_int, _P]),
+    "rh_update_mskp": (C.c_int, [_P, _SP]),
     "rh_timing_enable": (C.c_int, [_P, C.c_int]),
     "rh_timing_report": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "rh_timing_reset": (C.c_int, [_P]),

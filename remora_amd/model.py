@@ -213,6 +213,11 @@ class REMORA:
         ip = make_init_params(self.case)
         L.check(self.lib.rh_init_state(self.ctx, C.byref(self.state), C.byref(ip)))
 
+    def update_mskp(self):
+        """REMORA::update_mskp + the periodic ghost fill of the four masks (make_new_level.cpp:617-655, init_from_netcdf.cpp:408-412):
+        call after writing mskr / msku / mskv into the state (the case needs masks_all_one = 0 for the step to read them)."""
+        L.check(self.lib.rh_update_mskp(self.ctx, C.byref(self.state)))
+
     def begin_step(self):
         """Head of REMORA::timeStep (REMORA_TimeStep.cpp:48-61): advance the clock, swap old and new."""
         self.t_old = self.t_new
