@@ -48,6 +48,10 @@ def main():
     rx, ry = rank % px, rank // px
     jlo, jhi = slab_rows(ny, py, ry)
     ilo, ihi = slab_rows(nx, px, rx)
+    land = os.environ.get("REMORA_DECOMP_LAND", "") == "1"       # land in the domain: masks written by every box from the same layout
+    if land:
+        cfg = dict(cfg, masks_all_one=0)
+
     # REMORA_DECOMP_TRANSPORT=rccl: the library's built-in RCCL send/recv, one GPU per rank (LOCAL_RANK); the process group stays
     # gloo (it only carries the 128-byte communicator id and the gathers of this script).  Default: all ranks on cuda:0, host-staged.
     rccl = os.environ.get("REMORA_DECOMP_TRANSPORT", "") == "rccl"
@@ -61,6 +65,10 @@ def main():
 
     def run(r):
         r.InitData()
+        if land:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from landmask import put_masks_device
+            put_masks_device(r, cfg)
         if ncalls < 0:
             r.Evolve(nsteps)
         else:

@@ -40,6 +40,20 @@ def test_interior_rim_split_keeps_the_bits(case, world, port, grid, split):
     assert r.returncode == 0 and "DECOMP_OK" in out, out[-4000:]
 
 
+@pytest.mark.parametrize("case,world,port,grid", [("Seamount", 4, 29661, "2x2"), ("DoubleGyre", 3, 29662, "1x3"), ("Upwelling@300x210x6", 2, 29663, "1x2"),
+                                                  ("Upwelling_GLS", 2, 29664, "2x1")])
+def test_decomposed_with_land_equals_single_box(case, world, port, grid):
+    """Land in the domain (tests/landmask.py: islands, coasts on walls and across periodic sides, cut by the box boundaries): every
+    box writes its masks from the same layout, rh_update_mskp builds mskp and exchanges the mask ghost cells, and three steps must
+    equal the single-box run with the same land bit for bit (the third case is wide enough for the interior / rim split)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", REMORA_DECOMP_LAND="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "decomp_worker.py"), case, "3", grid]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "DECOMP_OK" in out, out[-4000:]
+
+
 def _ngpu():
     import torch
     return torch.cuda.device_count()
