@@ -113,6 +113,8 @@ def parse():
                     "allocation whose probe steps ran fastest (the step time depends on which physical pages a 57 GB block lands on, +-3 %% from "
                     "process to process on this hardware); 1 = take the first")
     ap.add_argument("--cpu-sample", type=str, default="512x512x50x4", help="nx x ny x nz x steps of the CPU-oracle sample")
+    ap.add_argument("--selfcheck-child", action="store_true", help="internal: one rank of the exchange-mode check that every rank of an N > 1 run "
+                    "starts as a child process before it touches its GPU (see exchange_selfcheck)")
     return ap.parse_args()
 
 
@@ -187,22 +189,54 @@ def spawn_ranks(n):
     sys.exit(rc)
 
 
+SELFCHECK_TIMEOUT_S = int(os.environ.get("REMORA_BENCH_SELFCHECK_TIMEOUT", "420"))
+
+
+def exchange_selfcheck(world):
+    """N > 1: which exchange mode the timed run uses is decided on the node it runs on, by a CHILD process per rank started before
+    this rank touches its GPU: the children form their own process group (MASTER_PORT moved aside), run two steps from the same
+    initial state with the exchanges on the compute stream and two with the side-stream mode (fills of setup_step on the side
+    stream; barotropic kernel split into interior and rim tiles with the exchanges under the interior), and print whether every
+    rank found the fields bit-identical.  A child that fails, or that has not answered after SELFCHECK_TIMEOUT_S (a hang in a mode
+    this node does not support must not take the measured run with it), is ended -- the exact process started here -- and the
+    answer is "single stream".  Returns (use_side_stream, reason)."""
+    port = int(os.environ.get("MASTER_PORT", "29500"))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
+    env["MASTER_PORT"] = str(port + 101 if port + 101 < 65000 else port - 101)
+    cmd = [sys.executable, os.path.abspath(__file__), "--selfcheck-child"] + [x for x in sys.argv[1:] if x != "--selfcheck-child"]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=SELFCHECK_TIMEOUT_S)   # ends the child on timeout
+    except subprocess.TimeoutExpired:
+        return False, f"the check did not finish within {SELFCHECK_TIMEOUT_S} s"
+    if r.returncode != 0:
+        return False, f"the check ended with exit code {r.returncode}"
+    if "SELFCHECK_RESULT 1" in r.stdout:
+        return True, "bit-identical to the single-stream run on this node"
+    return False, "the side-stream run did NOT reproduce the single-stream one on this node"
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(a.gpus)
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE = {world}")
+    host_transport = os.environ.get("REMORA_BENCH_TRANSPORT", "") == "host"
+    # the variable that switches the side-stream exchanges: RH_ASYNC_RCCL=1 turns them on over RCCL (off by default), RH_NO_ASYNC=1
+    # turns them off over the host-staged transport of the rehearsal (on by default)
+    mode_var, mode_on, mode_off = ("RH_NO_ASYNC", "0", "1") if host_transport else ("RH_ASYNC_RCCL", "1", "0")
+    side_verdict = None
+    if world > 1 and not a.selfcheck_child and mode_var not in os.environ:
+        side_verdict = exchange_selfcheck(world)          # before this process touches a GPU
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     # REMORA_BENCH_TRANSPORT=host: rehearsal of the N > 1 path on a box with fewer GPUs than ranks (ranks share cuda:0, messages are
     # staged through the host over gloo).  Never the measured configuration: the driver's runs use RCCL, one GPU per rank.
-    host_transport = os.environ.get("REMORA_BENCH_TRANSPORT", "") == "host"
     if host_transport:
         local = 0
     elif world > 1 and torch.cuda.device_count() < world:
@@ -232,30 +266,33 @@ def main():
         r.InitData()
         return r
 
-    # N > 1 over RCCL: the library keeps its exchanges on the compute stream unless RH_ASYNC_RCCL=1 (side-stream fills of
-    # setup_step; interior/rim split of the barotropic kernel with the exchanges under the interior tiles).  With the variable unset
-    # the bench decides on the node it runs on: two steps each way from the same initial state, and the side-stream mode is used
-    # for the timed run only if every rank finds its fields bit-identical to the single-stream ones.
-    exchange_mode = None
-    if world > 1 and not host_transport and "RH_ASYNC_RCCL" not in os.environ:
-        os.environ["RH_ASYNC_RCCL"] = "0"
+    if a.selfcheck_child:
+        # one rank of the check (see exchange_selfcheck): two steps each way from the same initial state, every field compared
+        os.environ[mode_var] = mode_off
         ref = make(); ref.timeStep(); ref.timeStep(); ref.sync()
-        os.environ["RH_ASYNC_RCCL"] = "1"
+        os.environ[mode_var] = mode_on
+        if os.environ.get("REMORA_BENCH_SELFCHECK_HANG", "") == "1":     # test hook: a side-stream mode that never comes back
+            time.sleep(10 ** 6)
         rem = make(); rem.timeStep(); rem.timeStep(); rem.sync()
         same = all(torch.equal(ref.view(f)[0], rem.view(f)[0]) for f in ("cons_new", "xvel_new", "yvel_new", "ubar", "vbar", "zeta", "Zt_avg1"))
-        t = torch.tensor([1 if same else 0], dtype=torch.int32, device=f"cuda:{local}")
+        t = torch.tensor([1 if same else 0], dtype=torch.int32, device="cpu" if host_transport else f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        if int(t.item()) == 1:
-            exchange_mode = "side stream: exchanges under the interior tiles (bit-identical to the single-stream run on this node, checked before timing)"
-            ref.close()
-        else:
-            exchange_mode = "single stream (the side-stream run did NOT reproduce it on this node: reported, not used)"
-            rem.close(); rem = ref
-            os.environ["RH_ASYNC_RCCL"] = "0"
-    else:
-        rem = make()
-        if world > 1:
-            exchange_mode = "host-staged rehearsal" if host_transport else f"RH_ASYNC_RCCL={os.environ.get('RH_ASYNC_RCCL')} (set by the caller)"
+        print(f"SELFCHECK_RESULT {int(t.item())}", flush=True)
+        ref.close(); rem.close()
+        dist.destroy_process_group()
+        return
+    exchange_mode = None
+    if side_verdict is not None:
+        # every rank must time the same mode: the ranks' verdicts are reduced once more (a child may have failed on one rank only)
+        t = torch.tensor([1 if side_verdict[0] else 0], dtype=torch.int32, device="cpu" if host_transport else f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        use_side = int(t.item()) == 1
+        os.environ[mode_var] = mode_on if use_side else mode_off
+        exchange_mode = (f"side stream: exchanges under the interior tiles ({side_verdict[1]}, checked in child processes before timing)" if use_side else
+                         f"single stream ({side_verdict[1] if not side_verdict[0] else 'another rank could not confirm the side-stream mode'}: reported, not used)")
+    elif world > 1:
+        exchange_mode = f"{mode_var}={os.environ.get(mode_var)} (set by the caller)"
+    rem = make()
     # Placement.  On this hardware the same binary on the same box runs the step 2-5 % faster or slower from one ALLOCATION of the
     # state to the next (same virtual address or not; every launch of a process alike: tools/placement_probe.py) --
     # which physical pages the block lands on decides how the ~13 concurrent streams of a kernel spread over the HBM channels.  A run
