@@ -25,7 +25,8 @@ def test_decomposed_equals_single_box(case, world, port, grid):
 
 @pytest.mark.parametrize("split", ["1", "0"])
 @pytest.mark.parametrize("case,world,port,grid", [("DoubleGyre@420x100x4", 2, 29651, "2x1"), ("Upwelling@300x210x6", 2, 29652, "1x2"),
-                                                  ("DoubleGyre@420x210x4", 4, 29653, "2x2"), ("Seamount@300x210x5", 3, 29654, "1x3")])
+                                                  ("DoubleGyre@420x210x4", 4, 29653, "2x2"), ("Seamount@300x210x5", 3, 29654, "1x3"),
+                                                  ("DoubleGyre@256x256x4", 4, 29655, "1x4")])      # j-slabs with inner ranks, the bench's default grid shape
 def test_interior_rim_split_keeps_the_bits(case, world, port, grid, split):
     """Boxes wide enough for k2d_fused to have interior tiles (>= 3 tiles of 63 x 7 points each way): inside rh_advance the barotropic
     loop then launches the interior tiles first, runs the flux frame, the DUon / DVom exchange and the previous call's ghost fill on
