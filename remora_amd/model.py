@@ -117,6 +117,26 @@ class REMORA:
         self.ncell = tuple(case["ncell"])
         torch.cuda.synchronize(self.device)
 
+    def rebind(self, buf=None):
+        """Move the state to another allocation (a fresh one, or `buf`, a tensor this object made earlier): the context, its
+        decomposition and its communicator stay, the arrays are bound at the new place and hold whatever the block holds (call
+        InitData or upload a state next).  The step's speed depends on where the block lands (Placement); bench.py uses
+        this to try a few blocks per rank without rebuilding the communicator.  Returns the previous tensor."""
+        torch = self.torch
+        self.sync()
+        old = self.buf
+        if buf is None:
+            buf = torch.zeros(self.lib.rh_state_bytes(self.ctx) // 8 + 32, dtype=torch.float64, device=self.device)
+        self.buf = buf
+        base = (buf.data_ptr() + 255) // 256 * 256
+        self._base_off = (base - buf.data_ptr()) // 8
+        L.check(self.lib.rh_state_bind(self.ctx, C.c_void_p(base), C.byref(self.state)))
+        self.istep = 0
+        self.t_new = 0.0
+        self.t_old = -1.0e200
+        torch.cuda.synchronize(self.device)
+        return old
+
     def close(self):
         if getattr(self, "ctx", None) is not None and self.ctx:
             self.lib.rh_destroy(self.ctx)

@@ -21,7 +21,7 @@ def _bench(extra_env, timeout=420, torchrun=False):
     if torchrun:                    # the driver's launch line for N > 1
         head += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29741"]
     cmd = head + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nx", "256", "--ny", "160", "--nz", "6", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline"]
+           "--no-cpu-baseline", "--place-tries", "2"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-3000:])
@@ -33,6 +33,7 @@ def test_two_ranks_pick_the_side_stream_mode_after_checking_it(torchrun):
     d = _bench({}, torchrun=torchrun)
     assert d["n_gpus"] == 2 and d["finite"] and d["value"] > 0 and d["scaling"] == "weak"
     assert d["exchange"].startswith("side stream"), d["exchange"]
+    assert d["placement"]["tries"] == 2 and d["placement"]["kept"] > 0          # per-rank search over state blocks (REMORA.rebind)
     # the barotropic kernel ran split into interior and rim tiles: two launches per fused call, priced as one call
     import re
     nfast = int(re.search(r"nfast (\d+)", d["config"]["workload"]).group(1))

@@ -106,3 +106,27 @@ def test_random_state_through_fused_drivers(case, ncell):
     hu, _, _ = rem.get("Huon"); hv, _, _ = rem.get("Hvom")
     assert (hu > 0).any() and (hu < 0).any() and (hv > 0).any() and (hv < 0).any()
     rem.close(); orc.close()
+
+
+def test_rebind_moves_the_state_and_keeps_the_bits():
+    """REMORA.rebind binds the state to another allocation under the same context: the same run from the new block must give the
+    same bits, and going back to the first block as well (bench.py's placement search relies on it)."""
+    import numpy as np
+    from remora_amd import cases
+    from remora_amd.model import REMORA
+    rem = REMORA(cases.get("Seamount"))
+    out = []
+    first = None
+    for leg in range(3):
+        if leg == 1:
+            first = rem.rebind()
+            assert first.data_ptr() != rem.buf.data_ptr()
+        if leg == 2:
+            rem.rebind(first)
+            assert rem.buf.data_ptr() == first.data_ptr()
+        rem.InitData()
+        rem.Evolve(3)
+        out.append({n: rem.get(n)[0] for n in ("cons_new", "xvel_new", "yvel_new", "zeta", "ubar", "vbar", "Hz")})
+    for n in out[0]:
+        assert np.array_equal(out[0][n], out[1][n]) and np.array_equal(out[0][n], out[2][n]), n
+    rem.close()
