@@ -447,6 +447,13 @@ def main():
                  "note": "frac_3d = union bytes of the fused 3-D kernels / (setup_step + advance_3d_ml time); frac_step adds the k2d_fused bytes "
                          "and divides by the whole step; frac_3d_reference_granular prices the same time against the 1232 B/cell the "
                          "reference's own pass structure moves (SURVEY.md 8d)"}
+    # the barotropic loop: its share of the step, launches per call and what a call costs outside the fused kernel (launch gaps,
+    # the first and last calls' small kernels, ghost fills of open or periodic sides)
+    baro = None
+    if "k2d_fused" in rep and "advance_2d" in rep:
+        n2 = rep["advance_2d"]["calls"] / nprof
+        baro = {"ms_per_step": round(rep["advance_2d"]["ms"] / nprof, 3), "k2d_fused_ms_per_step": round(rep["k2d_fused"]["ms"] / nprof, 3),
+                "calls_per_step": n2, "overhead_us_per_call": round((rep["advance_2d"]["ms"] - rep["k2d_fused"]["ms"]) / nprof / n2 * 1e3, 2)}
     if rank == 0:
         out = {"metric": "3D baroclinic cell-updates/s", "value": cells_per_gpu * world * a.steps / el, "unit": "cell-updates/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True,
@@ -456,7 +463,7 @@ def main():
                                       f"{f'{px}x{py} i-j decomposition, ghost exchange over ' + ('gloo (host-staged)' if host_transport else 'RCCL') if world > 1 else 'single box'}",
                           "parallelism": f"ij-decomp {px}x{py}"},
                "finite": finite, "build": build, **({"exchange": exchange_mode} if exchange_mode else {}), **({"placement": placement} if placement else {}), **({"transport": "host-staged gloo rehearsal (NOT the RCCL configuration)"} if host_transport else {}),
-               "roofline": roof, "step_roofline": step_roof, "kernels": kern,
+               "roofline": roof, "step_roofline": step_roof, **({"barotropic_loop": baro} if baro else {}), "kernels": kern,
                "kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}}
         if not a.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a.cpu_sample)

@@ -36,3 +36,16 @@ def test_update_mskp_rule_and_periodic_ghosts():
         for ii in range(plo[0], phi[0] + 1):
             assert p[0, 0, jj - plo[1], ii - plo[0]] == p[0, 0, (jj % ny) - plo[1], (ii % nx) - plo[0]], (ii, jj)
     orc.close()
+
+
+def test_timing_build_of_the_oracle_is_current():
+    """bench.py's cpu_baseline leg loads oracle/liboracle_fast.so as prebuilt on the GPU box: it must export everything the Python
+    binding declares, i.e. be built from the same sources as the parity build (__graft_entry__.build makes both)."""
+    import ctypes as C
+    import os
+    from oracle import oracle_py
+    fast = C.CDLL(os.path.join(os.path.dirname(oracle_py.__file__), "liboracle_fast.so"))
+    for name in ("o_create", "o_destroy", "o_advance", "o_setup_step", "o_advance_2d_onestep", "o_advance_3d_ml", "o_begin_step", "o_end_step",
+                 "o_update_mskp", "o_nfast", "o_istep", "o_field", "o_plot", "o_est_timestep", "o_sum_iq", "o_set_weights", "o_physbc_calc",
+                 "o_fillpatch_calc", "o_get_bc", "o_init_bcs"):
+        assert hasattr(fast, name), name
