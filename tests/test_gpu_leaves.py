@@ -93,28 +93,41 @@ def _rand(rng, lo_v, hi_v, nc, nk, lo, hi):
     return Arr(rng.uniform(lo_v, hi_v, (nc, nk, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1)), (lo[0], lo[1], 0))
 
 
-def _ctx(nz, periodic):
+def _ctx(nz, periodic, land=False):
     cfg = cases.get("Seamount" if periodic else "DoubleGyre")
     cfg["ncell"] = (NX, NY, nz)
+    if land:
+        cfg["masks_all_one"] = 0            # the kernels read the mask arrays they are given
     return cfg, REMORA(cfg)
+
+
+def _mask(land, shape2d, lo, values=(0.0, 1.0), seed=777):
+    """a 2-D mask array: ones, or (land) seeded random picks from `values` -- about a third of the points dry"""
+    if not land:
+        return Arr(np.ones((1, 1) + shape2d), lo)
+    rng = np.random.default_rng(seed)
+    pick = rng.choice(len(values) + 1, size=shape2d)          # one extra slot for "wet" so that water dominates
+    m = np.where(pick >= len(values), 1.0, np.asarray(values)[np.minimum(pick, len(values) - 1)])
+    return Arr(m[None, None], lo)
 
 
 def _metrics(rng, g):
     return (_rand(rng, 1e-3, 2e-3, 1, 1, (-g, -g - 1), (NX - 1 + g, NY + g)), _rand(rng, 1e-3, 2e-3, 1, 1, (-g - 1, -g), (NX + g, NY - 1 + g)))
 
 
+@pytest.mark.parametrize("land", [False, True])
 @pytest.mark.parametrize("periodic", [True, False])
-def test_rhs_t_3d_leaf(periodic):
+def test_rhs_t_3d_leaf(periodic, land):
     """REMORA::rhs_t_3d, REMORA_rhs_t_3d.cpp:27-335"""
     nz = 7; N = nz - 1
-    cfg, rem = _ctx(nz, periodic)
+    cfg, rem = _ctx(nz, periodic, land)
     rng = np.random.default_rng(12345)
     g = 3
     t = _rand(rng, 5.0, 25.0, 1, nz, (-g, -g), (NX - 1 + g, NY - 1 + g)); ss = _rand(rng, 5.0, 25.0, 1, nz, (-g, -g), (NX - 1 + g, NY - 1 + g))
     Huon = _rand(rng, -50.0, 50.0, 1, nz, (-g, -g), (NX + g, NY - 1 + g)); Hvom = _rand(rng, -50.0, 50.0, 1, nz, (-g, -g), (NX - 1 + g, NY + g))
     Hz = _rand(rng, 1.0, 20.0, 1, nz, (-g, -g), (NX - 1 + g, NY - 1 + g)); W = _rand(rng, -5.0, 5.0, 1, nz + 1, (-g, -g), (NX - 1 + g, NY - 1 + g))
     pm, pn = _metrics(rng, g)
-    msku = Arr(np.ones((1, 1, NY + 2 * g, NX + 1 + 2 * g)), (-g, -g, 0)); mskv = Arr(np.ones((1, 1, NY + 1 + 2 * g, NX + 2 * g)), (-g, -g, 0))
+    msku = _mask(land, (NY + 2 * g, NX + 1 + 2 * g), (-g, -g, 0), seed=1); mskv = _mask(land, (NY + 1 + 2 * g, NX + 2 * g), (-g, -g, 0), seed=2)
     FC = Arr(np.zeros((1, nz + 1, NY + 2 * g, NX + 2 * g)), (-g, -g, 0))
     dt = 300.0
     bx = ((0, 0, 0), (NX - 1, NY - 1, N))
@@ -158,10 +171,11 @@ def test_rhs_uv_3d_leaf(periodic):
     rem.close()
 
 
-def test_uv3dmix_leaf():
+@pytest.mark.parametrize("land", [False, True])
+def test_uv3dmix_leaf(land):
     """REMORA::uv3dmix, REMORA_uv3dmix.cpp:6-149 (3-D call)"""
     nz = 7; N = nz - 1
-    cfg, rem = _ctx(nz, False)
+    cfg, rem = _ctx(nz, False, land)
     rng = np.random.default_rng(12345)
     g = 3
     cb = ((-g, -g), (NX - 1 + g, NY - 1 + g)); ub = ((-g, -g), (NX + g, NY - 1 + g)); vb = ((-g, -g), (NX - 1 + g, NY + g)); pb = ((-g, -g), (NX + g, NY + g))
@@ -171,7 +185,7 @@ def test_uv3dmix_leaf():
     visc2_p = _rand(rng, 1.0, 100.0, 1, 2, *pb); visc2_r = _rand(rng, 1.0, 100.0, 1, 2, *cb)
     Hz = _rand(rng, 1.0, 20.0, 1, nz, *cb)
     pm = _rand(rng, 1e-3, 2e-3, 1, 1, (-g - 1, -g - 1), (NX + g, NY + g)); pn = _rand(rng, 1e-3, 2e-3, 1, 1, (-g - 1, -g - 1), (NX + g, NY + g))
-    mskp = Arr(np.ones((1, 1, NY + 1 + 2 * g, NX + 1 + 2 * g)), (-g, -g, 0))
+    mskp = _mask(land, (NY + 1 + 2 * g, NX + 1 + 2 * g), (-g, -g, 0), values=(0.0, 2.0), seed=3)      # update_mskp's values: 0, 1, 2
     xbx = ((0, 0, 0), (NX, NY - 1, N)); ybx = ((0, 0, 0), (NX - 1, NY, N))
     dt = 300.0
     O.leaf("o_uv3dmix")(O.obox(*xbx), O.obox(*ybx), u.fab(), v.fab(), uold.fab(), vold.fab(), rufrc.fab(), rvfrc.fab(), visc2_p.fab(), visc2_r.fab(), Hz.fab(),
@@ -226,19 +240,20 @@ def test_rhs_uv_2d_leaf(periodic):
 
 
 @pytest.mark.parametrize("periodic", [True, False])
+@pytest.mark.parametrize("land", [False, True])
 @pytest.mark.parametrize("ioff,joff", [(1, 0), (0, 1)])
-def test_update_massflux_3d_leaf(periodic, ioff, joff):
+def test_update_massflux_3d_leaf(periodic, ioff, joff, land):
     """REMORA::update_massflux_3d, REMORA_update_massflux_3d.cpp:24-122, on the grow-2 box the driver uses (walls: the boundary-face
     velocity correction of :87-101)"""
     nz = 7; N = nz - 1
-    cfg, rem = _ctx(nz, periodic)
+    cfg, rem = _ctx(nz, periodic, land)
     rng = np.random.default_rng(12345)
     g = 3
     fb = ((-g, -g), (NX - 1 + ioff + g, NY - 1 + joff + g)); cb = ((-g, -g), (NX - 1 + g, NY - 1 + g))
     phi = _rand(rng, -0.5, 0.5, 1, nz, *fb); Hphi = _rand(rng, -50.0, 50.0, 1, nz, *fb); Hz = _rand(rng, 1.0, 20.0, 1, nz, *cb)
     phibar = _rand(rng, -0.5, 0.5, 3, 1, *fb); pmn = _rand(rng, 1e-3, 2e-3, 1, 1, (-g - 1, -g - 1), (NX + g, NY + g))
     a1 = _rand(rng, -500.0, 500.0, 1, 1, *fb); a2 = _rand(rng, -500.0, 500.0, 1, 1, *fb)
-    msk = Arr(np.ones((1, 1, fb[1][1] + g + 1, fb[1][0] + g + 1)), (-g, -g, 0))
+    msk = _mask(land, (fb[1][1] + g + 1, fb[1][0] + g + 1), (-g, -g, 0), seed=4)
     DC = Arr(np.zeros((1, nz + 2, fb[1][1] + g + 1, fb[1][0] + g + 1)), (-g, -g, -1)); FC = Arr(np.zeros((1, nz + 1, fb[1][1] + g + 1, fb[1][0] + g + 1)), (-g, -g, 0))
     DC.lo = (-g, -g, -1)
     bx = ((-2, -2, 0), (NX - 1 + 2, NY - 1 + 2, N))
@@ -252,11 +267,12 @@ def test_update_massflux_3d_leaf(periodic, ioff, joff):
     rem.close()
 
 
-def test_prestep_t_leaf():
+@pytest.mark.parametrize("land", [False, True])
+def test_prestep_t_leaf(land):
     """omega + REMORA::prestep_t_advection + the tracer call of prestep_diffusion (REMORA_prestep_t_advection.cpp:10-361,
     REMORA_prestep_diffusion.cpp:19-165 with lambda = 1) for one tracer, second-and-later-step weights (iic = 2)"""
     nz = 7; N = nz - 1
-    cfg, rem = _ctx(nz, True)
+    cfg, rem = _ctx(nz, True, land)
     rng = np.random.default_rng(12345)
     g = 3
     cb = ((-g, -g), (NX - 1 + g, NY - 1 + g)); ub = ((-g, -g), (NX + g, NY - 1 + g)); vb = ((-g, -g), (NX - 1 + g, NY + g))
@@ -268,7 +284,7 @@ def test_prestep_t_leaf():
     h = Arr(np.repeat(-z_w.h[:, :1], 2, axis=0), Hz.lo)
     W = Arr(np.zeros((1, nz + 1) + Hz.h.shape[2:]), Hz.lo)
     pm, pn = (_rand(rng, 1e-3, 2e-3, 1, 1, *cb), _rand(rng, 1e-3, 2e-3, 1, 1, *cb))
-    msku = Arr(np.ones((1, 1, NY + 2 * g, NX + 1 + 2 * g)), (-g, -g, 0)); mskv = Arr(np.ones((1, 1, NY + 1 + 2 * g, NX + 2 * g)), (-g, -g, 0))
+    msku = _mask(land, (NY + 2 * g, NX + 1 + 2 * g), (-g, -g, 0), seed=5); mskv = _mask(land, (NY + 1 + 2 * g, NX + 2 * g), (-g, -g, 0), seed=6)
     Akt = _rand(rng, 1e-5, 1e-2, 3, nz + 1, *cb); ru = _rand(rng, -1.0, 1.0, 2, nz, *ub)
     zero2 = Arr(np.zeros((1, 1) + Hz.h.shape[2:]), Hz.lo)
     DC = Arr(np.zeros((1, nz + 2) + Hz.h.shape[2:]), (-g, -g, -1)); FC = Arr(np.zeros((1, nz + 2) + Hz.h.shape[2:]), Hz.lo)
