@@ -1253,18 +1253,19 @@ __global__ void k_uv3dmix(B3 xb, B3 yb, B3 un, A4 u, A4 v, A4 uold, A4 vold, A4 
 }
 // LDS-tiled, k-marching form of k_uv3dmix (same arithmetic).  The direct form evaluates every stress twice and asks the fabric
 // for 15 doubles per cell where 5 are distinct (profiles/r1_v3_traffic.json).  Here a block stages uold, vold, Hz of one level
-// (64 x 8 footprint, halo 1); each thread evaluates the stresses of ITS rho point and ITS psi point once and parks them in LDS;
-// the u and v points combine their own values with the neighbour's.  Blocks overlap by one column and one row (stride 63 x 7,
+// (64 x 16 footprint, halo 1); each thread evaluates the stresses of ITS rho point and ITS psi point once and parks them in LDS;
+// the u and v points combine their own values with the neighbour's.  Blocks overlap by one column and one row (stride 63 x 15;
 // as in k2d_uvbar), so no thread computes a halo stress.  Input and stress tiles are double-buffered on the parity of k and the
 // update runs one level behind the stresses: one barrier per level.
 #define M3_SX (RT_BX - 1)
-#define M3_SY (RT_BY - 1)
-__global__ void __launch_bounds__(RT_BX * RT_BY)
+#define M3_BY 16          // rows per block: the staged footprint is (M3_BY + 2) / (M3_BY - 1) rows per row of output (8: 1.43, 16: 1.2)
+#define M3_SY (M3_BY - 1)
+__global__ void __launch_bounds__(RT_BX * M3_BY)
 k_uv3dmix_tiled(B3 xb, B3 yb, B3 un, A4 u, A4 v, A4 uold, A4 vold, A4 rufrc, A4 rvfrc, A4 visc2_p, A4 visc2_r, A4 Hz,
                 A4 pm, A4 pn, A4 mskp, int N, double dt)
 {
-    typedef Tile<1, 1> T1; typedef TView<1, 1> V1;
-    constexpr int NT = RT_BX * RT_BY, SET = 3 * T1::SIZE, FSET = 4 * NT;
+    typedef Tile<1, 1, M3_BY> T1; typedef TView<1, 1, M3_BY> V1;
+    constexpr int NT = RT_BX * M3_BY, SET = 3 * T1::SIZE, FSET = 4 * NT;
     __shared__ double lds[2 * SET + 2 * FSET];
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
     const RhTile rh_t_ = rh_tile();
@@ -1273,7 +1274,7 @@ k_uv3dmix_tiled(B3 xb, B3 yb, B3 un, A4 u, A4 v, A4 uold, A4 vold, A4 rufrc, A4 
     // rho points un.lo-1 .. un.hi and psi points un.lo .. un.hi+1 carry a stress some velocity point needs
     const bool ar = i >= un.lo0 - 1 && i <= un.hi0 && j >= un.lo1 - 1 && j <= un.hi1;
     const bool ap = i >= un.lo0 && i <= un.hi0 + 1 && j >= un.lo1 && j <= un.hi1 + 1;
-    const bool au = tx >= 1 && ty <= RT_BY - 2 && inb2(xb, i, j), av = tx <= RT_BX - 2 && ty >= 1 && inb2(yb, i, j);
+    const bool au = tx >= 1 && ty <= M3_BY - 2 && inb2(xb, i, j), av = tx <= RT_BX - 2 && ty >= 1 && inb2(yb, i, j);
     MixR r; MixP p; memset(&r, 0, sizeof r); memset(&p, 0, sizeof p);
     double fr_x = 0.0, fr_e = 0.0, fp_e = 0.0, fp_x = 0.0;
     if (ar) { r = mix_r_metrics(pm, pn, visc2_r, i, j); fr_x = r.on_r * r.on_r * r.visc; fr_e = r.om_r * r.om_r * r.visc; }
@@ -1288,7 +1289,7 @@ k_uv3dmix_tiled(B3 xb, B3 yb, B3 un, A4 u, A4 v, A4 uold, A4 vold, A4 rufrc, A4 
         const double spn2 = pn(i, j - 1, 0) + pn(i, j, 0), spm2 = pm(i, j - 1, 0) + pm(i, j, 0);
         cv = dt * 0.25 * spm * spn; hspn_v = 0.5 * spn2; hspm_v = 0.5 * spm2; frcv = rvfrc(i, j, 0);
     }
-    const HaloCell hu = halo_cell<1, 1>(uold, i0, j0, tx, ty), hv = halo_cell<1, 1>(vold, i0, j0, tx, ty), hh = halo_cell<1, 1>(Hz, i0, j0, tx, ty);
+    const HaloCell hu = halo_cell<1, 1, M3_BY>(uold, i0, j0, tx, ty), hv = halo_cell<1, 1, M3_BY>(vold, i0, j0, tx, ty), hh = halo_cell<1, 1, M3_BY>(Hz, i0, j0, tx, ty);
     double u0 = ld_in(uold, i, j, 0), v0 = ld_in(vold, i, j, 0), hz = ld_in(Hz, i, j, 0);
     double uh = halo_ld(uold, hu, 0), vh = halo_ld(vold, hv, 0), hzh = halo_ld(Hz, hh, 0);
     double un_k = au ? u(i, j, 0) : 0.0, vn_k = av ? v(i, j, 0) : 0.0;        // the fields being updated, level of the pending update
@@ -1356,7 +1357,7 @@ extern "C" int rh_uv3dmix(rh_ctx *c, rh_box xbx, rh_box ybx, rh_array4 u, rh_arr
             mkA(visc2_p), mkA(visc2_r), mkA(Hz), mkA(pm), mkA(pn), mkA(mskp), N, dt);
     else {
         const dim3 grid((un.hi[0] - un.lo[0] + 1 + M3_SX) / M3_SX, (un.hi[1] - un.lo[1] + 1 + M3_SY) / M3_SY, 1);
-        k_uv3dmix_tiled<<<grid, rt_block(), 0, c->stream>>>(mkB(xbx), mkB(ybx), mkB(un), mkA(u), mkA(v), mkA(uold), mkA(vold), mkA(rufrc), mkA(rvfrc),
+        k_uv3dmix_tiled<<<grid, dim3(RT_BX, M3_BY, 1), 0, c->stream>>>(mkB(xbx), mkB(ybx), mkB(un), mkA(u), mkA(v), mkA(uold), mkA(vold), mkA(rufrc), mkA(rvfrc),
             mkA(visc2_p), mkA(visc2_r), mkA(Hz), mkA(pm), mkA(pn), mkA(mskp), N, dt);
     }
     RH_LAUNCH_CHECK(); return 0;
