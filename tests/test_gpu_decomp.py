@@ -13,7 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("case,world,port,grid", [("Seamount", 2, 29611, "1x2"), ("Upwelling", 3, 29612, "1x3"), ("DoubleGyre", 3, 29613, "1x3"),
                                                   ("Advection", 2, 29614, "1x2"), ("Seamount", 4, 29615, "2x2"), ("Upwelling", 2, 29616, "2x1"),
                                                   ("DoubleGyre", 4, 29617, "2x2"), ("Advection", 3, 29618, "3x1"),
-                                                  ("Upwelling_GLS", 2, 29619, "1x2"), ("Upwelling_GLS", 4, 29620, "2x2")])
+                                                  ("Upwelling_GLS", 2, 29619, "1x2"), ("Upwelling_GLS", 4, 29620, "2x2"),
+                                                  # open (radiating / outflow) sides on all four faces, GLS on: the physical-boundary passes of a
+                                                  # box must act on the domain's faces only, and the radiation condition reads the previous level
+                                                  ("Channel_Test_orlanski", 2, 29621, "1x2"), ("Channel_Test_orlanski", 2, 29622, "2x1"),
+                                                  ("Channel_Test_orlanski", 4, 29623, "2x2")])
 def test_decomposed_equals_single_box(case, world, port, grid):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
