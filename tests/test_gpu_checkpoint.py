@@ -108,3 +108,28 @@ def test_plotfile_rewrite_does_not_grow(tmp_path):
     assert pb.cell_offset == 0 and pb.nd_offset == 0
     assert os.path.getsize(os.path.join(d, "Level_0", "Cell_D_00000")) == n1
     b.close()
+
+
+@pytest.mark.parametrize("case", ["Seamount", "DoubleGyre"])
+def test_restart_with_land_is_bit_identical(case, tmp_path):
+    """The same with land in the domain (tests/landmask.py).  The checkpoint holds mskr / msku / mskv as the reference's does
+    (IO/REMORA_Checkpoint.cpp:172-182, 424-434) but not mskp, which the reference leaves at init_masks' ones on a restart; a caller that
+    wants the run continued unchanged rebuilds it from the restored mskr (rh_update_mskp), as done here."""
+    from landmask import put_masks_device
+    cfg = dict(cases.get(case), masks_all_one=0)
+    a = REMORA(cfg); a.InitData(); put_masks_device(a, cfg); a.Evolve(8)
+    b = REMORA(cfg); b.InitData(); put_masks_device(b, cfg); b.Evolve(4)
+    chk = tmp_path / "chk00004"
+    b.WriteCheckpointFile(chk)
+    b.close()
+    c = REMORA(cfg)
+    c.ReadCheckpointFile(chk)
+    for m in ("mskr", "msku", "mskv"):
+        assert np.array_equal(a.get(m)[0], c.get(m)[0]), m
+    assert (c.get("mskp")[0] == 1.0).all()                       # what the reference's restart leaves
+    c.update_mskp()
+    assert np.array_equal(a.get("mskp")[0], c.get("mskp")[0])
+    c.Evolve(4)
+    bad = [f for f in CARRIED if not np.array_equal(a.get(f)[0], c.get(f)[0])]
+    assert not bad, f"{case}: restarted run with land differs in {bad}"
+    a.close(); c.close()
