@@ -9,6 +9,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "liboracle.so")
+# REMORA_ORACLE_CHK=1: the bounds-checking build (oracle/Makefile: liboracle_chk.so, every Fab access tested against its box; an
+# access outside aborts the process with the place).  Built on demand; slow; for tests that exercise arms no gold file covers.
+_CHK = os.environ.get("REMORA_ORACLE_CHK", "") == "1"
+if _CHK:
+    _LIB = os.path.join(_HERE, "liboracle_chk.so")
 
 
 class GlsParams(C.Structure):
@@ -35,7 +40,7 @@ def build(force=False):
     if force or not os.path.exists(_LIB) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB)
             for f in ("leaves.c", "bc.c", "driver.c", "gls.c", "oracle.h", "fab.h")):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, os.path.basename(_LIB)], stdout=subprocess.DEVNULL)
     return _LIB
 
 
@@ -57,7 +62,7 @@ def use_fast_build():
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB):
+        if not os.path.exists(_LIB) or _CHK:
             build()
         _lib = C.CDLL(_LIB)
         _lib.o_create.restype = C.c_void_p

@@ -93,9 +93,12 @@ def _rand(rng, lo_v, hi_v, nc, nk, lo, hi):
     return Arr(rng.uniform(lo_v, hi_v, (nc, nk, hi[1] - lo[1] + 1, hi[0] - lo[0] + 1)), (lo[0], lo[1], 0))
 
 
-def _ctx(nz, periodic, land=False):
+def _ctx(nz, periodic, land=False, **flags):
+    """flags: SolverChoice switches the leaf reads (tracer_c4, uv_c2, flat_bathymetry); the pinned cases all run the defaults, so
+    the other arms are PARITY UNPINNED (no gold file) and stand on the oracle's source reading"""
     cfg = cases.get("Seamount" if periodic else "DoubleGyre")
     cfg["ncell"] = (NX, NY, nz)
+    cfg.update(flags)
     if land:
         cfg["masks_all_one"] = 0            # the kernels read the mask arrays they are given
     return cfg, REMORA(cfg)
@@ -115,12 +118,14 @@ def _metrics(rng, g):
     return (_rand(rng, 1e-3, 2e-3, 1, 1, (-g, -g - 1), (NX - 1 + g, NY + g)), _rand(rng, 1e-3, 2e-3, 1, 1, (-g - 1, -g), (NX + g, NY - 1 + g)))
 
 
+@pytest.mark.parametrize("c4,flat", [(0, 0), (1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("land", [False, True])
 @pytest.mark.parametrize("periodic", [True, False])
-def test_rhs_t_3d_leaf(periodic, land):
-    """REMORA::rhs_t_3d, REMORA_rhs_t_3d.cpp:27-335"""
+def test_rhs_t_3d_leaf(periodic, land, c4, flat):
+    """REMORA::rhs_t_3d, REMORA_rhs_t_3d.cpp:27-335: upstream3 / centered4 (:112-141,148-177,209-240,244-275), each with the
+    flat-bathymetry form of the correction term"""
     nz = 7; N = nz - 1
-    cfg, rem = _ctx(nz, periodic, land)
+    cfg, rem = _ctx(nz, periodic, land, tracer_c4=c4, flat_bathymetry=flat)
     rng = np.random.default_rng(12345)
     g = 3
     t = _rand(rng, 5.0, 25.0, 1, nz, (-g, -g), (NX - 1 + g, NY - 1 + g)); ss = _rand(rng, 5.0, 25.0, 1, nz, (-g, -g), (NX - 1 + g, NY - 1 + g))
@@ -139,12 +144,13 @@ def test_rhs_t_3d_leaf(periodic, land):
     rem.close()
 
 
+@pytest.mark.parametrize("c2", [0, 1])
 @pytest.mark.parametrize("periodic", [True, False])
-def test_rhs_uv_3d_leaf(periodic):
+def test_rhs_uv_3d_leaf(periodic, c2):
     """REMORA::coriolis + REMORA::rhs_uv_3d (REMORA_coriolis.cpp:10-40, REMORA_rhs_uv_3d.cpp:31-385): domain-edge curvature branches
-    with walls, none with periodic sides"""
+    with walls, none with periodic sides; upstream3 and centered2 (:148-157,302-311) momentum fluxes"""
     nz = 7; N = nz - 1
-    cfg, rem = _ctx(nz, periodic)
+    cfg, rem = _ctx(nz, periodic, uv_c2=c2)
     rng = np.random.default_rng(12345)
     g = 3
     cb = ((-g, -g), (NX - 1 + g, NY - 1 + g)); ub = ((-g, -g), (NX + g, NY - 1 + g)); vb = ((-g, -g), (NX - 1 + g, NY + g))
@@ -220,10 +226,12 @@ def test_vert_visc_3d_leaf(nz, ioff, joff):
     rem.close()
 
 
+@pytest.mark.parametrize("c2", [0, 1])
 @pytest.mark.parametrize("periodic", [True, False])
-def test_rhs_uv_2d_leaf(periodic):
-    """REMORA::rhs_uv_2d, REMORA_rhs_uv_2d.cpp:20-238 (the entry point the fused barotropic kernel never calls)"""
-    cfg, rem = _ctx(7, periodic)
+def test_rhs_uv_2d_leaf(periodic, c2):
+    """REMORA::rhs_uv_2d, REMORA_rhs_uv_2d.cpp:20-238 (the entry point the fused barotropic kernel never calls); upstream3 and
+    centered2 (:130,217)"""
+    cfg, rem = _ctx(7, periodic, uv_c2=c2)
     rng = np.random.default_rng(12345)
     g = 3
     ub = ((-g, -g), (NX + g, NY - 1 + g)); vb = ((-g, -g), (NX - 1 + g, NY + g))
@@ -267,12 +275,14 @@ def test_update_massflux_3d_leaf(periodic, ioff, joff, land):
     rem.close()
 
 
+@pytest.mark.parametrize("c4,flat", [(0, 0), (1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("land", [False, True])
-def test_prestep_t_leaf(land):
+def test_prestep_t_leaf(land, c4, flat):
     """omega + REMORA::prestep_t_advection + the tracer call of prestep_diffusion (REMORA_prestep_t_advection.cpp:10-361,
-    REMORA_prestep_diffusion.cpp:19-165 with lambda = 1) for one tracer, second-and-later-step weights (iic = 2)"""
+    REMORA_prestep_diffusion.cpp:19-165 with lambda = 1) for one tracer, second-and-later-step weights (iic = 2); upstream3,
+    centered4 (:222-234,255-266) and the flat-bathymetry centred flux (:147-157, which ignores the scheme)"""
     nz = 7; N = nz - 1
-    cfg, rem = _ctx(nz, True, land)
+    cfg, rem = _ctx(nz, True, land, tracer_c4=c4, flat_bathymetry=flat)
     rng = np.random.default_rng(12345)
     g = 3
     cb = ((-g, -g), (NX - 1 + g, NY - 1 + g)); ub = ((-g, -g), (NX + g, NY - 1 + g)); vb = ((-g, -g), (NX - 1 + g, NY + g))
