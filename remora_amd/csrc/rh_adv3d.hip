@@ -494,6 +494,9 @@ static inline bool vv_reg_depth(int nz) { return nz == 13 || nz == 16 || nz == 5
 template <int NZ> struct VVD { static constexpr int T = NZ > 50 ? 8 : VV_D_T, V = NZ > 50 ? 5 : VV_D_V, U = NZ > 50 ? 7 : VV_D_U; };
 
 extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 phi, rh_array4 Hz, rh_array4 Akv, int N, double dt)
+{ return vert_visc_3d_view(c, phi_bx, ioff, joff, phi, Hz, Akv, mkA(Akv), N, dt); }
+// akA: what the kernels read as Akv -- the array itself (the entry point above) or the constant rows of mkA_vmix (the drivers)
+int vert_visc_3d_view(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 phi, rh_array4 Hz, rh_array4 Akv, A4 akA, int N, double dt)
 {
     TScope t(c, "vert_visc_3d");
     if ((ioff != 0 && ioff != 1) || (joff != 0 && joff != 1) || (ioff && joff)) return rh_fail("rh_vert_visc_3d: bad (ioff,joff)");
@@ -513,17 +516,17 @@ extern "C" int rh_vert_visc_3d(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_
         const size_t lds_reg = sizeof(double) * 2 * (size_t)(N + 1) * 64;
         if (vv_reg_depth(N + 1) && !c->noregsolve) {     // a depth the register form is built for: no operand is read twice
 #define RH_VVR(NZ) do { \
-            if (ioff) k_column_solver_reg<1, 0, 0, VVD<NZ>::U, NZ><<<gridu, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0, mfz); \
-            else if (joff) k_column_solver_reg<0, 1, 0, VVD<NZ>::V, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0, mfz); \
-            else k_column_solver_reg<0, 0, 0, VVD<NZ>::T, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0, mfz); } while (0)
+            if (ioff) k_column_solver_reg<1, 0, 0, VVD<NZ>::U, NZ><<<gridu, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0, mfz); \
+            else if (joff) k_column_solver_reg<0, 1, 0, VVD<NZ>::V, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0, mfz); \
+            else k_column_solver_reg<0, 0, 0, VVD<NZ>::T, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0, mfz); } while (0)
             switch (N + 1) { case 13: RH_VVR(13); break; case 16: RH_VVR(16); break; case 64: RH_VVR(64); break; default: RH_VVR(50); break; }
 #undef RH_VVR
         }
-        else if (ioff) k_column_solver<1, 0, 0, VV_D_U><<<gridu, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
-        else if (joff) k_column_solver<0, 1, 0, VV_D_V><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
-        else k_column_solver<0, 0, 0, VV_D_T><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), mkA(Akv), z, z, z, z, z, N, dt, 0.0);
+        else if (ioff) k_column_solver<1, 0, 0, VV_D_U><<<gridu, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0);
+        else if (joff) k_column_solver<0, 1, 0, VV_D_V><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0);
+        else k_column_solver<0, 0, 0, VV_D_T><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0);
     } else                                               // deeper columns: coefficients in the global work-space slab
-        k_vert_visc<<<grid2(phi_bx), rh_block(), 0, c->stream>>>(mkB(phi_bx), ioff, joff, mkA(phi), mkA(Hz), mkA(Akv), mkA(c->wCF), mkA(c->wDC), N, dt);
+        k_vert_visc<<<grid2(phi_bx), rh_block(), 0, c->stream>>>(mkB(phi_bx), ioff, joff, mkA(phi), mkA(Hz), akA, mkA(c->wCF), mkA(c->wDC), N, dt);
     RH_LAUNCH_CHECK(); return 0;
 }
 
@@ -553,6 +556,7 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     // update_massflux_3d rides on the same sweep (the column's final velocity and thickness are in LDS when the corrector ends):
     // *applied = 2 tells the caller to run update_massflux_3d only on what this launch leaves out (ghost faces, wall faces)
     MfTail mfu, mfv; memset(&mfu, 0, sizeof mfu); memset(&mfv, 0, sizeof mfv);
+    const A4 akvA = mkA_vmix(c, s, 0);
     const bool mf = reg && !c->no_mffuse;
     if (mf) {
         RH_NEED(s->Huon, xbx); RH_NEED(s->Hvom, ybx); RH_NEED(s->ubar, bx_slab(xbx, 2, 0)); RH_NEED(s->vbar, bx_slab(ybx, 2, 0));
@@ -564,18 +568,18 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
         mfu.Hphi = mkA(s->Huon); mfu.phibar = mkA(s->ubar); mfu.Davg2 = mkA(s->DU_avg2);
         mfv.Hphi = mkA(s->Hvom); mfv.phibar = mkA(s->vbar); mfv.Davg2 = mkA(s->DV_avg2);
     }
-#define RH_VVU(NZ) k_column_solver_reg<1, 0, 1, VVD<NZ>::U, NZ><<<gx, 64, lds_reg, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn), \
+#define RH_VVU(NZ) k_column_solver_reg<1, 0, 1, VVD<NZ>::U, NZ><<<gx, 64, lds_reg, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), akvA, mkA(s->DU_avg1), mkA(s->pn), \
         mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab, mfu)
-#define RH_VVV(NZ) k_column_solver_reg<0, 1, 1, VVD<NZ>::V, NZ><<<gy, 64, lds_reg, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm), \
+#define RH_VVV(NZ) k_column_solver_reg<0, 1, 1, VVD<NZ>::V, NZ><<<gy, 64, lds_reg, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), akvA, mkA(s->DV_avg1), mkA(s->pm), \
         mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab, mfv)
     { TScope t(c, "uv_corrector");
     if (reg) { switch (N + 1) { case 13: RH_VVU(13); break; case 16: RH_VVU(16); break; case 64: RH_VVU(64); break; default: RH_VVU(50); break; } }
-    else k_column_solver<1, 0, 1, VV_D_U><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), mkA(s->Akv), mkA(s->DU_avg1), mkA(s->pn),
+    else k_column_solver<1, 0, 1, VV_D_U><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), akvA, mkA(s->DU_avg1), mkA(s->pn),
         mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab);
     RH_LAUNCH_CHECK(); }
     TScope t(c, "uv_corrector");
     if (reg) { switch (N + 1) { case 13: RH_VVV(13); break; case 16: RH_VVV(16); break; case 64: RH_VVV(64); break; default: RH_VVV(50); break; } }
-    else k_column_solver<0, 1, 1, VV_D_V><<<gy, 64, lds_bytes, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), mkA(s->Akv), mkA(s->DV_avg1), mkA(s->pm),
+    else k_column_solver<0, 1, 1, VV_D_V><<<gy, 64, lds_bytes, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), akvA, mkA(s->DV_avg1), mkA(s->pm),
         mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab);
     RH_LAUNCH_CHECK();
     *applied = mf ? 2 : 1;

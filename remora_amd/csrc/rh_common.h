@@ -177,9 +177,29 @@ struct rh_ctx {
     bool unfused = false;            // RH_UNFUSED=1: drivers call the per-leaf entry points instead of the fused kernels (A/B parity)
     bool gls_libm_pow = false;       // RH_GLS_LIBM_POW=1: every per-point power of the GLS closure through pow() (A/B parity and timing)
     bool no_bc2d = false;            // RH_NO_BC2D=1: the ghost cells of the barotropic step always through the batched BC passes, never in k2d_fused (A/B parity and timing)
+    bool no_rhofuse = false;         // RH_NO_RHOFUSE=1: rho_eos (+ P) and prsgrd as two launches handing rho and P over through memory (A/B parity and timing)
     bool poison = false;             // RH_POISON=1: NaN-fill the work space at the start of every step (stale-read detector)
+    // RH_VMIX_CONST (init_custom_vmix of the Seamount / DoubleGyre kind): set_analytical_vmix (REMORA.cpp:565-573) rewrites the same
+    // constants into Akv / Akt at every step.  Here k_vmix and its FillPatch run once per bound state (vmix_akv_done / vmix_akt_done
+    // remember which arrays hold the constants), and the column solvers the drivers launch read the constants from four short rows
+    // (d_vmixrow: Akv, Akt x 3; zero row / level strides, so every load hits L1) instead of streaming the 3-D arrays.  Same values,
+    // same expressions: bit-identical.  RH_VMIX_REWRITE=1 goes back to the per-step rewrite and the array reads (A/B parity and timing).
+    double *d_vmixrow = nullptr; int vmixrow_len = 0; const double *vmix_akv_done = nullptr, *vmix_akt_done = nullptr; bool vmix_rewrite = false;
     ~rh_ctx() { if (bcq) bc_queue_delete(bcq); if (haloq) halo_queue_delete(haloq); }
 };
+
+// view of Akv (which = 0) or of component n of Akt (which = 1 + n) for the column solvers the drivers launch: the constant rows
+// when the arrays are known to hold the constants (see rh_ctx::d_vmixrow), the arrays themselves otherwise
+static inline A4 mkA_vmix(const rh_ctx *c, const rh_state *s, int which)
+{
+    const rh_array4 &real = which == 0 ? s->Akv : s->Akt;
+    A4 r = which == 0 ? mkA(real) : mkA(real, which - 1);
+    const bool rows = c->prm.vmix_mode == RH_VMIX_CONST && !c->vmix_rewrite && c->d_vmixrow && c->vmix_akv_done == s->Akv.p &&
+                      c->vmix_akt_done == s->Akt.p && real.hi[0] - real.lo[0] + 1 <= c->vmixrow_len;
+    if (rows) { r.p = c->d_vmixrow + (long)which * c->vmixrow_len; r.sy = 0; r.sz = 0; r.sn = 0; }
+    return r;
+}
+int  vert_visc_3d_view(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 phi, rh_array4 Hz, rh_array4 Akv, A4 akv_view, int N, double dt);   // rh_adv3d.hip
 
 // timing scope: records events around a kernel group when enabled
 struct TScope {
@@ -226,6 +246,7 @@ int  launch_massflux_rest(rh_ctx *c, rh_box full, rh_box done, int ioff, int jof
                           rh_array4 Hz, rh_array4 pm_or_pn, rh_array4 Dphi_avg1, rh_array4 Dphi_avg2, rh_array4 msk, int N);
 int  launch_mask_cons(rh_ctx *c, rh_state *s);
 int  launch_rho_eos_P(rh_ctx *c, rh_state *s, rh_box bx, rh_box pbx);
+int  launch_rho_prsgrd(rh_ctx *c, rh_state *s, rh_box gbx2, rh_box xbx, rh_box ybx, int nrhs, int N, int *applied);
 int  launch_prestep_uv2(rh_ctx *c, rh_state *s, rh_box bx, rh_box dead_u, rh_box dead_v, int iic, int ntfirst, int nrhs, int N, double dt);
 int  launch_prestep_uv(rh_ctx *c, rh_box vel_bx, rh_box dead, int ioff, int joff, rh_array4 vel, rh_array4 vel_old, rh_array4 rvel,
                        rh_array4 Hz, rh_array4 sstr, rh_array4 bstr, rh_array4 pm, rh_array4 pn, int iic, int ntfirst, int nrhs, int N, double dt);

@@ -370,6 +370,7 @@ extern "C" long rh_state_bytes(const rh_ctx *c)
 extern "C" int rh_state_bind(const rh_ctx *c, void *device_base, rh_state *out)
 {
     if (((size_t)device_base) & 255) return rh_fail("rh_state_bind: base must be 256-byte aligned");
+    const_cast<rh_ctx *>(c)->vmix_akv_done = const_cast<rh_ctx *>(c)->vmix_akt_done = nullptr;     // whatever the block holds, it is not yet the constants
     double *p = (double *)device_base;
     for (const FieldSpec &f : g_fields) {
         if (f.gls_only && c->prm.vmix_mode != RH_VMIX_GLS) { rh_array4 z; memset(&z, 0, sizeof z); z.hi[0] = z.hi[1] = z.hi[2] = -1; out->*(f.m) = z; continue; }
@@ -395,6 +396,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     auto bad = [&](const char *m) {
         const std::string msg = m;                          // m may point into g_rh_err
         if (c->d_sc) (void)hipFree(c->d_sc);
+        if (c->d_vmixrow) (void)hipFree(c->d_vmixrow);
         if (c->d_work) (void)hipFree(c->d_work);
         delete c;
         return rh_fail("rh_create: %s", msg.c_str());
@@ -429,6 +431,8 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     c->no_split2d = getenv("RH_NO_SPLIT2D") && atoi(getenv("RH_NO_SPLIT2D")) != 0;
     c->no_bc2d = getenv("RH_NO_BC2D") && atoi(getenv("RH_NO_BC2D")) != 0;
     c->poison = getenv("RH_POISON") && atoi(getenv("RH_POISON")) != 0;
+    c->no_rhofuse = getenv("RH_NO_RHOFUSE") && atoi(getenv("RH_NO_RHOFUSE")) != 0;
+    c->vmix_rewrite = getenv("RH_VMIX_REWRITE") && atoi(getenv("RH_VMIX_REWRITE")) != 0;
 
     // stretching curves (here N = nz, DepthStretchTransform.H:49)
     const int nz = c->nz;
@@ -440,6 +444,17 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     e = hipMemcpy(c->d_sc, c->h_sc.data(), sizeof(double) * c->h_sc.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bad_hip("hipMemcpy", e);
 
+    if (prm->vmix_mode == RH_VMIX_CONST) {                   // the four constant rows of rh_ctx::d_vmixrow, as long as a row of Akv
+        const rh_array4 ak = shape_of(c, 0, 0, 1, 1, 2, 2, 0);
+        c->vmixrow_len = (int)align32(ak.hi[0] - ak.lo[0] + 1 + 8);
+        std::vector<double> rows((size_t)4 * c->vmixrow_len);
+        for (int w = 0; w < 4; w++)
+            for (int q = 0; q < c->vmixrow_len; q++) rows[(size_t)w * c->vmixrow_len + q] = w == 0 ? prm->Akv_const : prm->Akt_const[w - 1];
+        e = hipMalloc((void **)&c->d_vmixrow, sizeof(double) * rows.size());
+        if (e != hipSuccess) { c->d_vmixrow = nullptr; return bad_hip("hipMalloc", e); }
+        e = hipMemcpy(c->d_vmixrow, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return bad_hip("hipMemcpy", e);
+    }
     // work space: rho (setup_step.cpp:63), P (prsgrd.cpp:39), W (setup_step.cpp:210, advance_3d.cpp:230),
     // CF/DC of the tridiagonal solve (advance_3d.cpp:49-51, vert_visc_3d.cpp), DUon/DVom (advance_2d.cpp:105-106)
     c->rho  = shape_of(c, 0, 0, 0, 1, 2, 2, 0);
@@ -487,7 +502,7 @@ extern "C" int rh_destroy(rh_ctx *c)
     if (c->d_xbuf2) (void)hipFree(c->d_xbuf2);
     for (auto &v : c->tev) for (auto &p : v) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &e : c->evpool) (void)hipEventDestroy(e);
-    (void)hipFree(c->d_sc); (void)hipFree(c->d_work); if (c->d_xbuf) (void)hipFree(c->d_xbuf); if (c->d_diag) (void)hipFree(c->d_diag);
+    (void)hipFree(c->d_sc); if (c->d_vmixrow) (void)hipFree(c->d_vmixrow); (void)hipFree(c->d_work); if (c->d_xbuf) (void)hipFree(c->d_xbuf); if (c->d_diag) (void)hipFree(c->d_diag);
     comm_release(c);
     delete c;
     return 0;

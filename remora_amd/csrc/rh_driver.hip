@@ -27,13 +27,18 @@ static int set_smflux(rh_ctx *c, rh_state *s, double time)
 // REMORA::set_analytical_vmix, Source/REMORA.cpp:565-573
 static int set_analytical_vmix(rh_ctx *c, rh_state *s)
 {
+    // constants that these arrays already hold (written by an earlier step, nothing else writes Akv / Akt without GLS): see rh_ctx::d_vmixrow
+    if (c->prm.vmix_mode == RH_VMIX_CONST && !c->vmix_rewrite && c->vmix_akv_done == s->Akv.p && c->vmix_akt_done == s->Akt.p) return 0;
+    c->vmix_akv_done = c->vmix_akt_done = nullptr;
     TScope t(c, "vmix");
     RH_TRY(launch_vmix(c, s));
     BcScope bcs(c);
     RH_TRY(halo_fillpatch(c, mfv(c, s->Akv, 0, 0, 1), s->mskr, RH_BCV_ZVEL, 0, 1));
     // the reference loops over NCONS but fills component 0 each time (REMORA.cpp:570-572): once is the same
     RH_TRY(halo_fillpatch(c, mfv(c, s->Akt, 0, 0, 1), s->mskr, RH_BCV_ZVEL, 0, 1));
-    return bcs.end();
+    RH_TRY(bcs.end());
+    if (c->prm.vmix_mode == RH_VMIX_CONST) { c->vmix_akv_done = s->Akv.p; c->vmix_akt_done = s->Akt.p; }
+    return 0;
 }
 
 __global__ void k_zero_box(B3 b, A4 a)
@@ -100,8 +105,11 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
     // in between reads Huon / Hvom
     const bool defer_mf = P.use_prestep && !c->unfused;
     if (!defer_mf) { TScope t(c, "massflux_old"); RH_TRY(launch_massflux_old(c, s)); }
-    if (c->unfused) RH_TRY(rh_rho_eos(c, bx_grow(bx, 2, 2, 0), s->cons_old, c->rho, s->rhoA, s->rhoS, s->bvf, s->Hz, s->z_w, s->z_r, s->h, s->mskr, N));   // :200
-    else RH_TRY(launch_rho_eos_P(c, s, bx_grow(bx, 2, 2, 0), bx_grow(bx, 1, 1, 0)));     // + the hydrostatic pressure of prsgrd (:229-260), same operands
+    // :200 rho_eos.  Its operands (cons_old, Hz, z_r, z_w, h, mskr) are not written before prsgrd (:262-266), and its results (bvf,
+    // rhoA, rhoS) are first read after it (gls_prestep, the barotropic steps): the fused form runs both at prsgrd's place
+    const bool rho_late = !c->unfused && !c->no_rhofuse;
+    if (c->unfused) RH_TRY(rh_rho_eos(c, bx_grow(bx, 2, 2, 0), s->cons_old, c->rho, s->rhoA, s->rhoS, s->bvf, s->Hz, s->z_w, s->z_r, s->h, s->mskr, N));
+    else if (!rho_late) RH_TRY(launch_rho_eos_P(c, s, bx_grow(bx, 2, 2, 0), bx_grow(bx, 1, 1, 0)));     // + the hydrostatic pressure of prsgrd (:229-260), same operands
     if (P.vmix_mode != RH_VMIX_GLS) RH_TRY(set_analytical_vmix(c, s));                             // :202-205
     RH_TRY(launch_set_zeta(c, s));                                                                 // :208
     // :210-211 mf_W.setVal(0): omega overwrites every level of the grow-1 box, so only the frame around it needs the zero
@@ -137,7 +145,12 @@ extern "C" int rh_setup_step(rh_ctx *c, rh_state *s, int istep, double t_old)
         RH_TRY(bcs.end());
     }
     const rh_box xbx = bx_nodal(bx, 0), ybx = bx_nodal(bx, 1);
-    RH_TRY(rh_prsgrd(c, bx_grow(bx, 1, 1, 0), xbx, ybx, s->ru, s->rv, s->pn, s->pm, c->rho, c->P, s->Hz, s->z_r, s->z_w, s->msku, s->mskv, nrhs, N));
+    int rp = 0;
+    if (rho_late) RH_TRY(launch_rho_prsgrd(c, s, bx_grow(bx, 2, 2, 0), xbx, ybx, nrhs, N, &rp));
+    if (!rp) {
+        if (rho_late) RH_TRY(launch_rho_eos_P(c, s, bx_grow(bx, 2, 2, 0), bx_grow(bx, 1, 1, 0)));
+        RH_TRY(rh_prsgrd(c, bx_grow(bx, 1, 1, 0), xbx, ybx, s->ru, s->rv, s->pn, s->pm, c->rho, c->P, s->Hz, s->z_r, s->z_w, s->msku, s->mskv, nrhs, N));
+    }
     if (!fused_t) {
         RH_TRY(rh_t3dmix(c, bx, s->cons_new, s->cons_old, s->diff2, s->Hz, s->pm, s->pn, s->msku, s->mskv, dt, P.use_salt ? 2 : 1));   // :283-286
         RH_TRY(rh_t3dmix(c, bx, a4_comp(s->cons_new, 2), a4_comp(s->cons_old, 2), a4_comp(s->diff2, 2), s->Hz, s->pm, s->pn, s->msku, s->mskv, dt, 1));
@@ -177,8 +190,8 @@ static int advance_3d(rh_ctx *c, rh_state *s, int istep)
     RH_TRY(launch_uv_corrector(c, s, istep, &fused_uv));                                           // :104-150 in one column kernel per velocity
     if (!fused_uv) {
         RH_TRY(launch_uv_ab3(c, s, istep));                                                        // :104-123
-        RH_TRY(rh_vert_visc_3d(c, xbx, 1, 0, s->xvel_new, s->Hz, s->Akv, N, dt));                  // :132
-        RH_TRY(rh_vert_visc_3d(c, ybx, 0, 1, s->yvel_new, s->Hz, s->Akv, N, dt));                  // :138
+        RH_TRY(vert_visc_3d_view(c, xbx, 1, 0, s->xvel_new, s->Hz, s->Akv, mkA_vmix(c, s, 0), N, dt));   // :132
+        RH_TRY(vert_visc_3d_view(c, ybx, 0, 1, s->yvel_new, s->Hz, s->Akv, mkA_vmix(c, s, 0), N, dt));   // :138
         RH_TRY(rh_vert_mean_3d(c, xbx, 1, 0, s->xvel_new, s->Hz, s->DU_avg1, s->pn, s->msku, N));  // :144
         RH_TRY(rh_vert_mean_3d(c, ybx, 0, 1, s->yvel_new, s->Hz, s->DV_avg1, s->pm, s->mskv, N));  // :150
     }
@@ -204,7 +217,7 @@ static int advance_3d(rh_ctx *c, rh_state *s, int istep)
         RH_TRY(rh_rhs_t_3d(c, bx, a4_comp(s->cons_new, n), a4_comp(s->sstore, n), s->Huon, s->Hvom, s->Hz, s->pn, s->pm, c->W, s->msku, s->mskv, N, dt));
     { TScope t(c, "halo"); RH_TRY(halo_fillpatch(c, mfv(c, s->cons_new, 0, 0, 0), s->mskr, RH_BCV_CONS, 0, RH_NCONS, &s->cons_old, &s->msku, &s->mskv)); }   // :350
     for (int n = 0; n < RH_NCONS; n++)                                                             // :382-385
-        RH_TRY(rh_vert_visc_3d(c, bx, 0, 0, a4_comp(s->cons_new, n), s->Hz, a4_comp(s->Akt, n), N, dt));
+        RH_TRY(vert_visc_3d_view(c, bx, 0, 0, a4_comp(s->cons_new, n), s->Hz, a4_comp(s->Akt, n), mkA_vmix(c, s, 1 + n), N, dt));
     return 0;
 }
 
@@ -399,6 +412,7 @@ int dev_setbox(rh_ctx *c, const rh_array4 &a, int comp, rh_box b, double v)
 extern "C" int rh_init_state(rh_ctx *c, rh_state *s, const rh_init_params *ip)
 {
     const rh_params &P = c->prm;
+    c->vmix_akv_done = c->vmix_akt_done = nullptr;          // Akv / Akt are rewritten below: the next step forms the constants again
     const int N = c->N;
     const rh_box bx = c->bx, b2 = bx_slab(bx, 2, 0);
     if (ip->prob < 0 || ip->prob > 5) return rh_fail("rh_init_state: unknown problem %d", ip->prob);

@@ -277,6 +277,7 @@ extern "C" int rh_write_checkpoint(rh_ctx *c, rh_state *s, const char *dir, int 
 extern "C" int rh_read_checkpoint(rh_ctx *c, rh_state *s, const char *dir, int *step, double *time)
 {
     if (!dir) return rh_fail("rh_read_checkpoint: null directory");
+    c->vmix_akv_done = c->vmix_akt_done = nullptr;          // Akv / Akt come from the file: the next step forms the constants again
     const std::string d0 = dir, d1 = d0 + "/Level_0";
     {
         FILE *f = fopen((d0 + "/Header").c_str(), "r");

@@ -2,6 +2,10 @@
 
 * RH_NOFUSE2D=1 (three-kernel barotropic call), RH_NOREGSOLVE=1 (LDS-ring column solver at every depth), RH_NO_ASYNC=1 (no side
   stream), RH_NO_BC2D=1 (ghost cells of the barotropic step through the batched BC passes instead of the rim blocks of k2d_fused) and RH_NO_MFFUSE=1 (update_massflux_3d as its own launches instead of on the velocity corrector's sweep) must give the same bits as the default path: each is checked against the oracle on the bit-exact cases.
+* RH_VMIX_REWRITE=1: constant vertical mixing rewritten at every step and read from the arrays by the column solvers (the default
+  writes Akv / Akt once per bound state and gives the solvers the constants in four L1-resident rows).
+* RH_NO_RHOFUSE=1: rho_eos (+ the hydrostatic pressure) and prsgrd as two launches with rho and P in memory (the default marches them as
+  one kernel, k_rho_prsgrd, and keeps both in LDS).
 * RH_POISON=1 fills the library's work arrays with NaN at the top of every step: a kernel that read scratch it had not written
   in the same step would produce NaN (and differ from the oracle).
 * DoubleGyre physics, the bench workload's depth (50 levels) and boundary conditions (all walls), on 512 x 512 columns = 8 x 64
@@ -40,7 +44,7 @@ def _phases(cfg, nsteps, what):
     rem.close(); orc.close()
 
 
-@pytest.mark.parametrize("switch", ["RH_NOFUSE2D", "RH_NOREGSOLVE", "RH_POISON", "RH_NO_ASYNC", "RH_NO_BC2D", "RH_NO_MFFUSE"])
+@pytest.mark.parametrize("switch", ["RH_NOFUSE2D", "RH_NOREGSOLVE", "RH_POISON", "RH_NO_ASYNC", "RH_NO_BC2D", "RH_NO_MFFUSE", "RH_VMIX_REWRITE", "RH_NO_RHOFUSE"])
 @pytest.mark.parametrize("case", ["Seamount", "DoubleGyre"])
 def test_switch_keeps_the_bits(switch, case, monkeypatch):
     monkeypatch.setenv(switch, "1")
@@ -129,4 +133,25 @@ def test_rebind_moves_the_state_and_keeps_the_bits():
         out.append({n: rem.get(n)[0] for n in ("cons_new", "xvel_new", "yvel_new", "zeta", "ubar", "vbar", "Hz")})
     for n in out[0]:
         assert np.array_equal(out[0][n], out[1][n]) and np.array_equal(out[0][n], out[2][n]), n
+    rem.close()
+
+
+def test_const_vmix_arrays_hold_the_constants_and_survive_rebind():
+    """constant vertical mixing (RH_VMIX_CONST) is written once per bound state: after steps from a fresh bind, after rebind to a
+    zeroed block and after InitData the arrays must hold the constants (REMORA.cpp:565-573 rewrites them every step; a checkpoint
+    or a plotfile reads them).  From the first step on the library takes the arrays to hold the constants: a caller who writes
+    into them later must bind the state again (or run with RH_VMIX_REWRITE=1) -- include/remora_hip.h says so."""
+    import numpy as np
+    from remora_amd import cases
+    from remora_amd.model import REMORA
+    cfg = cases.get("Seamount")
+    rem = REMORA(cfg)
+    for leg in range(3):
+        if leg == 1:
+            rem.rebind()                                  # a zeroed block
+        rem.InitData()
+        rem.Evolve(2)
+        akv = rem.get("Akv")[0]; akt = rem.get("Akt")[0]
+        assert np.all(akv == 1.0e-5), leg
+        assert np.all(akt[0] == 1.0e-6) and np.all(akt[1] == 1.0e-6) and np.all(akt[2] == 0.0), leg
     rem.close()
