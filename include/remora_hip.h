@@ -133,6 +133,11 @@ int  rh_comm_init(rh_ctx *ctx, const void *id128, int rank, int nranks);
  * buffers that are ready on `stream`: send n_lo doubles from send_lo to rank peer_lo and receive n_lo doubles from it into
  * recv_lo, likewise for the upper neighbour; a peer of -1 means no neighbour on that side.  The block sent to the lower
  * neighbour is what that neighbour receives from its upper one.  On return the receive buffers must be complete on `stream`.
+ * Stream contract: ALL device work of an exchange is ordered on the `stream` argument, never on the caller's own stream -- the pack
+ * kernels that wrote the send buffers were launched on it and the unpack kernels that read the receive buffers will be.  It is the
+ * context's compute stream or, while an exchange runs under compute kernels (the ghost fills at the end of rh_setup_step, the
+ * interior / rim split of the barotropic loop; both on by default with a hook), the library's side stream.  A hook that hands the
+ * buffers to a host-driven transport (MPI) must synchronise exactly that stream first (hipStreamSynchronize((hipStream_t)stream)).
  * Return 0 on success. */
 typedef int (*rh_exchange_fn)(void *user, const double *send_lo, double *recv_lo, long n_lo, int peer_lo,
                               const double *send_hi, double *recv_hi, long n_hi, int peer_hi, void *stream);
@@ -287,7 +292,9 @@ int  rh_init_state(rh_ctx *ctx, rh_state *s, const rh_init_params *ip);
 /* REMORA::update_mskp (Initialization/REMORA_make_new_level.cpp:617-655) followed by the periodic ghost fill of mskr / msku / mskv /
  * mskp (REMORA::init_masks_from_netcdf, Initialization/REMORA_init_from_netcdf.cpp:408-412): what the reference does once the
  * land / sea masks have been read.  The caller has written mskr, msku, mskv of the state (1 = water, 0 = land) over their valid
- * boxes and, on non-periodic sides, their ghost cells; rh_params.masks_all_one must be 0 for the step to read them. */
+ * boxes and, beyond non-periodic sides of the domain, their ghost cells; ghost cells at rank seams and across periodic sides are
+ * filled here (mskr's BEFORE mskp is formed, so that the first valid node line of a box sees its neighbour's cells; the reference
+ * gets them from the FAB intersection copy of init_from_netcdf.cpp:400).  rh_params.masks_all_one must be 0 for the step to read them. */
 int  rh_update_mskp(rh_ctx *ctx, rh_state *s);
 int  rh_plot_vars(rh_ctx *ctx, rh_state *s, int with_scalar, double *out_device);
 

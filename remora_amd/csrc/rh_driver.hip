@@ -532,9 +532,14 @@ extern "C" int rh_update_mskp(rh_ctx *c, rh_state *s)
 {
     const rh_box b = bx_grow(bx_slab(c->bx, 2, 0), 1, 1, 0);
     RH_NEED(s->mskp, b); RH_NEED(s->mskr, bx_grow(b, 1, 1, 0));
+    // mskr's ghost cells at rank seams (and across periodic sides) first: the kernel reads mskr(i-1, j), (i, j-1), (i-1, j-1) on the
+    // box grown by one, and its first valid node line at a seam must see the neighbour's cells -- in the reference the FAB
+    // intersection copy of init_from_netcdf.cpp:400 has put them there before update_mskp runs.  (Across a PERIODIC side the
+    // reference still has init_masks' 1.0 in those ghost cells at that point; here they hold the wrapped mask.  No reference case
+    // has land: parity unpinned either way.)
+    RH_TRY(halo_fill_boundary(c, mfv(c, s->mskr, 0, 0, 0), 0, 1));
     k_update_mskp<<<grid2(b), rh_block(), 0, c->stream>>>(mkB(b), mkA(s->mskr), mkA(s->mskp));
     RH_LAUNCH_CHECK();
-    RH_TRY(halo_fill_boundary(c, mfv(c, s->mskr, 0, 0, 0), 0, 1));
     RH_TRY(halo_fill_boundary(c, mfv(c, s->msku, 1, 0, 0), 0, 1));
     RH_TRY(halo_fill_boundary(c, mfv(c, s->mskv, 0, 1, 0), 0, 1));
     RH_TRY(halo_fill_boundary(c, mfv(c, s->mskp, 1, 1, 0), 0, 1));

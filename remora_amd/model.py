@@ -172,9 +172,11 @@ class REMORA:
         hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         hip.hipStreamSynchronize.argtypes = [C.c_void_p]
         torch = self.torch
+        self.hook_streams = []                                          # the stream of every hook call (tests: side stream or compute stream)
 
         def xfn(user, s_lo, r_lo, n_lo, p_lo, s_hi, r_hi, n_hi, p_hi, stream):
             try:
+                self.hook_streams.append(stream or 0)
                 reqs, recvs, sends = [], [], []
                 for sp, n, peer, tag in ((s_lo, n_lo, p_lo, 0), (s_hi, n_hi, p_hi, 1)):      # tag 0: travels down, 1: up
                     if peer >= 0 and n > 0:

@@ -48,7 +48,8 @@ def main():
     rx, ry = rank % px, rank // px
     jlo, jhi = slab_rows(ny, py, ry)
     ilo, ihi = slab_rows(nx, px, rx)
-    land = os.environ.get("REMORA_DECOMP_LAND", "") == "1"       # land in the domain: masks written by every box from the same layout
+    land = os.environ.get("REMORA_DECOMP_LAND", "") in ("1", "valid")       # land in the domain: masks written by every box from the same layout
+    land_valid_only = os.environ.get("REMORA_DECOMP_LAND", "") == "valid"   # ... over the valid boxes only: rh_update_mskp must fill the seams
     if land:
         cfg = dict(cfg, masks_all_one=0)
 
@@ -68,7 +69,7 @@ def main():
         if land:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from landmask import put_masks_device
-            put_masks_device(r, cfg)
+            put_masks_device(r, cfg, valid_only=land_valid_only)
         if ncalls < 0:
             r.Evolve(nsteps)
         else:
@@ -85,8 +86,19 @@ def main():
         per_step = 2 * rem.nfast                            # predictor and corrector of my_iif = 0 .. nfast - 1
         want = {"1": 2, "0": 1}[os.environ["REMORA_DECOMP_EXPECT_SPLIT"]] * per_step * nsteps
         assert rep["k2d_fused"]["calls"] == want, (rep["k2d_fused"], want)
+        # include/remora_hip.h, rh_exchange_fn: the hook is handed the stream its exchange is ordered on.  With the split the
+        # exchanges of the barotropic loop run on the library's side stream (not the context's compute stream, the null stream here)
+        # while the interior tiles are queued on the compute stream; without it (and with the setup_step fills still on the side
+        # stream) the loop's exchanges come on the compute stream.
+        if not rccl:
+            side = sum(1 for q in rem.hook_streams if q != 0)
+            loop_calls = per_step * nsteps                  # at least one exchange phase per fused barotropic call
+            if os.environ["REMORA_DECOMP_EXPECT_SPLIT"] == "1":
+                assert side >= loop_calls, (side, loop_calls, len(rem.hook_streams))
+            else:
+                assert len(rem.hook_streams) - side >= loop_calls, (side, loop_calls, len(rem.hook_streams))
     mine = {}
-    fields = FIELDS + (["tke", "gls", "Lscale", "Akk", "Akp", "Akt"] if "gls" in cfg else [])
+    fields = FIELDS + (["tke", "gls", "Lscale", "Akk", "Akp", "Akt"] if "gls" in cfg else []) + (["mskp", "mskr", "msku", "mskv"] if land else [])
     for f in fields:
         a, lo, hi = rem.get(f)
         mine[f] = (a, lo, hi)

@@ -30,11 +30,27 @@ def mask_arrays(f, lo, hi, di, dj):
     return f(i, j) * f(i - di, j - dj)
 
 
-def put_masks_device(rem, cfg):
-    """Write mskr / msku / mskv over the whole arrays of a device state (any box of a decomposition), then rh_update_mskp."""
+def put_masks_device(rem, cfg, valid_only=False):
+    """Write mskr / msku / mskv over the whole arrays of a device state (any box of a decomposition), then rh_update_mskp.
+    valid_only: write what include/remora_hip.h asks of the caller and no more -- the box's valid cells / faces plus the ghost cells
+    beyond a non-periodic side of the DOMAIN; ghost cells that belong to a neighbour box or to the periodic image keep init_masks'
+    1.0 (make_new_level.cpp:381-389) and must be filled by rh_update_mskp itself."""
     f = water(cfg)
+    nx, ny = cfg["ncell"][0], cfg["ncell"][1]
     for name, di, dj in (("mskr", 0, 0), ("msku", 1, 0), ("mskv", 0, 1)):
-        _, lo, hi = rem.get(name)
-        rem.set(name, mask_arrays(f, lo, hi, di, dj)[None, None], lo)
+        a, lo, hi = rem.get(name)
+        m = mask_arrays(f, lo, hi, di, dj)
+        if valid_only:
+            blo = [rem.params.box_lo[d] for d in range(2)]; bhi = [rem.params.box_hi[d] + (di, dj)[d] for d in range(2)]
+            dhi = (nx - 1 + di, ny - 1 + dj)
+            j, i = np.mgrid[lo[1]:hi[1] + 1, lo[0]:hi[0] + 1]
+            keep = np.ones_like(m, bool)
+            for d, q in ((0, i), (1, j)):
+                inside = (q >= blo[d]) & (q <= bhi[d])
+                if not cfg["periodic"][d]:
+                    inside |= (q < 0) & (blo[d] == 0) | (q > dhi[d]) & (bhi[d] == dhi[d])
+                keep &= inside
+            m = np.where(keep, m, 1.0)
+        rem.set(name, m[None, None], lo)
     rem.set("mskp", np.ones_like(rem.get("mskp")[0]))      # init_masks, make_new_level.cpp:381-389
     rem.update_mskp()

@@ -59,6 +59,20 @@ def test_decomposed_with_land_equals_single_box(case, world, port, grid):
     assert r.returncode == 0 and "DECOMP_OK" in out, out[-4000:]
 
 
+@pytest.mark.parametrize("case,world,port,grid", [("DoubleGyre", 2, 29671, "1x2"), ("DoubleGyre", 2, 29672, "2x1"), ("Seamount", 4, 29673, "2x2")])
+def test_update_mskp_fills_the_seams(case, world, port, grid):
+    """Every box writes mskr / msku / mskv over its VALID box only (plus the ghost cells beyond a wall of the domain), as
+    include/remora_hip.h asks; the ghost cells at rank seams keep init_masks' 1.0.  rh_update_mskp must bring the neighbour's cells
+    in before it forms mskp on its first valid node line (the reference's FAB intersection copy, init_from_netcdf.cpp:400, does):
+    the masks, mskp included, and three steps must equal the single-box run bit for bit."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="2", REMORA_DECOMP_LAND="valid")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "decomp_worker.py"), case, "3", grid]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "DECOMP_OK" in out, out[-4000:]
+
+
 def _ngpu():
     import torch
     return torch.cuda.device_count()

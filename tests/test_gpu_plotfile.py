@@ -31,6 +31,12 @@ def test_written_plotfile_matches_gold(case, tmp_path):
     _, mnd = read_plotfile(case, root=str(tmp_path), nodal=True)
     res = fcompare(gnd, mnd)
     assert all(r[2] for r in res), res
+    # the reference's regression criterion through the command-line tool (Tests/CTestList.cmake:39)
+    import subprocess, sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rh_fcompare.py")
+    r = subprocess.run([sys.executable, tool, "-a", "-r", "1e-11", "--abs_tol", "1e-11", os.path.join(GOLD, case), str(tmp_path / case)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "PLOTFILES AGREE" in r.stdout, r.stdout + r.stderr
     assert open(os.path.join(tmp_path, case, "Header")).read() == open(os.path.join(GOLD, case, "Header")).read()
     for h in ("Cell_H", "Nu_nd_H"):
         a = open(os.path.join(tmp_path, case, "Level_0", h)).read().split("\n")
