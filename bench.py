@@ -6,6 +6,11 @@ of the DoubleGyre physics (Exec/DoubleGyre, Tests/test_files/DoubleGyre/DoubleGy
 (BASELINE.json configs[3]).  With N > 1 the domain is 2048 x (2048 N) x 50, split into N j-slabs
 (weak scaling; --grid PXxPY picks another i-j process grid), and every FillBoundary becomes RCCL send/recv with the neighbours.
 
+`--workload config4` (or REMORA_BENCH_WORKLOAD=config4 in the environment, for drivers that pass no flags) runs BASELINE.json configs[4]
+instead: Upwelling physics, 4096 x 2048 x 64 cells per GPU on a 4 x 2 (8 GPUs), 2 x 2 (4), 2 x 1 (2) or 1 x 1 process grid.
+At N > 1 the control plane (communicator id, verdicts, timing reductions) is a gloo process group: the library's own RCCL communicator
+is the only RCCL instance in the process.
+
 Launch: `python bench.py --gpus N` from a bare shell starts its own N ranks (fresh child processes, started before this
 process touches a GPU); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one rank of N.
 
@@ -42,6 +47,7 @@ ALGO_DOUBLES = {
     "vert_visc_3d": 3 + 1,         # phi, Hz, Akt -> phi
     "update_massflux_3d": 3 + 1,   # phi, Hphi, Hz -> Hphi (+ phi on boundary faces only)
     "massflux_omega_new": 6 + 3,   # u, v, Huon, Hvom, Hz, z_w -> Huon, Hvom, W   (advance_3d: update_massflux_3d x2 + omega in one sweep)
+    "rho_prsgrd": 4 + 3,           # T, S, Hz, z_r -> bvf, ru, rv   (k_rho_prsgrd: rho_eos + hydrostatic pressure + prsgrd in one march; rho, P stay in LDS)
     "prsgrd": 4 + 2,               # rho, P, z_r, Hz -> ru, rv
     "rho_eos": 4 + 3,              # T, S, Hz, z_r -> rho, bvf, P   (the hydrostatic pressure of prsgrd rides on the same sweep)
     "omega": 3 + 1,                # Huon, Hvom, z_w -> W
@@ -62,12 +68,15 @@ ALGO_DOUBLES = {
 # nfast predictor and nfast corrector calls run fused per step: 30.5 on average (PMC: 32 doubles per column moved).
 K2D_DOUBLES = 30.5
 UV_CORRECTOR_MF = 5 + 2            # u, ru, Hz, Akv, Huon -> u, Huon   (the report then has a "massflux_rest" group and no "update_massflux_3d")
+# constant vertical mixing (RH_VMIX_CONST, e.g. DoubleGyre): the solvers read Akv / Akt from L1-resident rows, not from the 3-D arrays,
+# and k_vmix does not run after the first step -- one read fewer per solve
+CONST_VMIX_LESS = {"uv_corrector": 1, "vert_visc_3d": 1}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic_current.json")
 # kernel(s) behind each group in the rocprofv3 output (the traffic file's keys start with these)
 GROUP_KERNELS = {
     "prestep_t3": ["k_tracers_tiled<0"], "rhs_t3": ["k_tracers_tiled<1"], "rhs_uv_3d": ["k_rhs_uv_tiled"], "uv3dmix": ["k_uv3dmix_tiled"],
     "uv_corrector": ["k_column_solver_reg<1, 0, 1", "k_column_solver_reg<0, 1, 1"], "vert_visc_3d": ["k_column_solver_reg<0, 0, 0"],
-    "update_massflux_3d": ["k_massflux_lds"], "massflux_omega_new": ["k_massflux_omega_new"], "prsgrd": ["k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos_P"],
+    "update_massflux_3d": ["k_massflux_lds"], "massflux_omega_new": ["k_massflux_omega_new"], "prsgrd": ["k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos_P"], "rho_prsgrd": ["k_rho_prsgrd"],
     "omega": ["k_omega_lds"], "massflux_omega": ["k_massflux_omega<"], "prestep_uv": ["k_prestep_uv2"], "stretch_transform": ["k_stretch"],
     "vmix": ["k_vmix"], "massflux_old": ["k_massflux_old"], "k2d_fused": ["k2d_fused"],
 }
@@ -107,6 +116,9 @@ def parse():
     ap.add_argument("--nz", type=int, default=50)
     ap.add_argument("--case", type=str, default="DoubleGyre", help="physics of the synthetic grid: DoubleGyre (BASELINE configs[3], the measured workload) or "
                     "Upwelling (configs[4]-shaped blocks, e.g. --case Upwelling --nx 4096 --ny 2048 --nz 64)")
+    ap.add_argument("--workload", type=str, default=os.environ.get("REMORA_BENCH_WORKLOAD", "configs3"), choices=["configs3", "config4"],
+                    help="configs3 (default): DoubleGyre physics, --nx x --ny x --nz per GPU, 1 x N grid; config4: BASELINE configs[4], Upwelling physics "
+                    "4096 x 2048 x 64 per GPU on a 4x2 / 2x2 / 2x1 / 1x1 grid (overrides --case / --nx / --ny / --nz / --grid unless --grid is given)")
     ap.add_argument("--grid", type=str, default="", help="process grid PXxPY (PX * PY = --gpus); default 1xN = j-slabs, every rank keeps full 512-B-coalesced i rows")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--place-tries", type=int, default=4, help="allocate the state up to this many times before the timed run and keep the "
@@ -115,7 +127,14 @@ def parse():
     ap.add_argument("--cpu-sample", type=str, default="512x512x50x4", help="nx x ny x nz x steps of the CPU-oracle sample")
     ap.add_argument("--selfcheck-child", action="store_true", help="internal: one rank of the exchange-mode check that every rank of an N > 1 run "
                     "starts as a child process before it touches its GPU (see exchange_selfcheck)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.workload == "config4":
+        a.case = "Upwelling"
+        if (a.nx, a.ny, a.nz) == (2048, 2048, 50):          # sizes left at their defaults: the configs[4] block
+            a.nx, a.ny, a.nz = 4096, 2048, 64
+        if not a.grid:
+            a.grid = {1: "1x1", 2: "2x1", 4: "2x2", 8: "4x2"}.get(a.gpus, f"1x{a.gpus}")
+    return a
 
 
 def bench_case(nx_per_gpu, ny_per_gpu, nz, px, py=None, name="DoubleGyre"):
@@ -167,24 +186,50 @@ def free_port():
 
 def spawn_ranks(n):
     """`python bench.py --gpus N` from a bare shell: start N fresh rank processes (this parent never touches a GPU and never
-    imports torch), relay rank 0's JSON line, exit with the first non-zero code."""
+    imports torch), relay rank 0's JSON line, exit with the first non-zero code.  All children are polled: when one ends badly the
+    others (exactly the processes started here) are ended too instead of waiting in a rendezvous or a collective for the process
+    group's timeout; stderr of every rank is inherited, so their diagnostics stay visible."""
     port = free_port()
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True, start_new_session=True))
+    import signal
+    import threading
+
+    def end_group(p, sig):
+        """the rank and whatever it started (its exchange-mode check runs in a child of its own): the process group created above"""
         try:
-            p.wait(timeout=120 if rc == 0 else 5)
-        except subprocess.TimeoutExpired:
-            p.kill()                 # the exact child we started
-            p.wait()
-        rc = rc or p.returncode
-    sys.stdout.write(out0 or "")
+            os.killpg(p.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)     # drain rank 0's pipe while polling
+    rd.start()
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            time.sleep(2.0)                                   # let the failing rank's siblings print what they have to say
+            for p in procs:
+                end_group(p, signal.SIGTERM)
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    end_group(p, signal.SIGKILL)              # the exact process groups started here
+                    p.wait()
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    rd.join(timeout=10)
+    sys.stdout.write("".join(x or "" for x in out0))
     sys.stdout.flush()
     sys.exit(rc)
 
@@ -224,13 +269,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE = {world}")
+    if os.environ.get("REMORA_BENCH_TEST_DIE_RANK", "") == str(rank) and not a.selfcheck_child:      # test hook: a rank that ends before the rendezvous
+        sys.exit(7)
     host_transport = os.environ.get("REMORA_BENCH_TRANSPORT", "") == "host"
     # the variable that switches the side-stream exchanges: RH_ASYNC_RCCL=1 turns them on over RCCL (off by default), RH_NO_ASYNC=1
     # turns them off over the host-staged transport of the rehearsal (on by default)
     mode_var, mode_on, mode_off = ("RH_NO_ASYNC", "0", "1") if host_transport else ("RH_ASYNC_RCCL", "1", "0")
     side_verdict = None
+    wall = {}
+    t_start = time.perf_counter()
     if world > 1 and not a.selfcheck_child and mode_var not in os.environ:
         side_verdict = exchange_selfcheck(world)          # before this process touches a GPU
+        wall["selfcheck_s"] = round(time.perf_counter() - t_start, 2)
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -243,10 +293,9 @@ def main():
         raise SystemExit(f"--gpus {world} needs {world} visible GPUs (found {torch.cuda.device_count()}); REMORA_BENCH_TRANSPORT=host rehearses on fewer")
     torch.cuda.set_device(local)
     if world > 1:
-        if host_transport:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        # control plane (communicator id, verdicts, timing reductions: a few hundred bytes): gloo, so that the library's own RCCL
+        # communicator (rh_comm_init, dlopen'd librccl) is the only RCCL instance in the process; tests/decomp_worker.py does the same
+        dist.init_process_group("gloo")
 
     from remora_amd.model import REMORA
     px, py = (int(x) for x in a.grid.split("x")) if a.grid else (1, world)
@@ -275,7 +324,7 @@ def main():
             time.sleep(10 ** 6)
         rem = make(); rem.timeStep(); rem.timeStep(); rem.sync()
         same = all(torch.equal(ref.view(f)[0], rem.view(f)[0]) for f in ("cons_new", "xvel_new", "yvel_new", "ubar", "vbar", "zeta", "Zt_avg1"))
-        t = torch.tensor([1 if same else 0], dtype=torch.int32, device="cpu" if host_transport else f"cuda:{local}")
+        t = torch.tensor([1 if same else 0], dtype=torch.int32, device="cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         print(f"SELFCHECK_RESULT {int(t.item())}", flush=True)
         ref.close(); rem.close()
@@ -284,7 +333,7 @@ def main():
     exchange_mode = None
     if side_verdict is not None:
         # every rank must time the same mode: the ranks' verdicts are reduced once more (a child may have failed on one rank only)
-        t = torch.tensor([1 if side_verdict[0] else 0], dtype=torch.int32, device="cpu" if host_transport else f"cuda:{local}")
+        t = torch.tensor([1 if side_verdict[0] else 0], dtype=torch.int32, device="cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         use_side = int(t.item()) == 1
         os.environ[mode_var] = mode_on if use_side else mode_off
@@ -292,7 +341,42 @@ def main():
                          f"single stream ({side_verdict[1] if not side_verdict[0] else 'another rank could not confirm the side-stream mode'}: reported, not used)")
     elif world > 1:
         exchange_mode = f"{mode_var}={os.environ.get(mode_var)} (set by the caller)"
+    t_make = time.perf_counter()
     rem = make()
+    wall["create_and_init_s"] = round(time.perf_counter() - t_make, 2)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(r, warmup, steps):
+        """W untimed steps, then K timed steps between barriers; seconds, max over ranks"""
+        for _ in range(warmup):
+            r.timeStep()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.timeStep()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # The state as it was first allocated: what a caller that binds its arrays once (REMORA's MultiFabs through the glue) gets.  Timed
+    # with the same W / K as the headline, before any placement search; reported next to it.
+    first_alloc = None
+    if a.place_tries > 1:
+        t_fa = time.perf_counter()
+        el_fa = timed(rem, a.warmup, a.steps)
+        first_alloc = {"ms_per_step": el_fa / a.steps * 1e3, "value": a.nx * a.ny * a.nz * world * a.steps / el_fa}
+        wall["first_allocation_run_s"] = round(time.perf_counter() - t_fa, 2)
+        rem.InitData(); rem.istep = 0; rem.t_new = 0.0; rem.t_old = -1.0e200
+    t_place = time.perf_counter()
     # Placement.  On this hardware the same binary on the same box runs the step 2-5 % faster or slower from one ALLOCATION of the
     # state to the next (same virtual address or not; every launch of a process alike: tools/placement_probe.py, DESIGN.md section 6) --
     # which physical pages the block lands on decides how the ~13 concurrent streams of a kernel spread over the HBM channels.  A run
@@ -328,7 +412,7 @@ def main():
         # step together, so a rank judges a block by its own kernels only -- the event-timed groups that neither exchange nor wait
         # (HIP events on the library's stream) -- and keeps the block on which those ran fastest; every rank tries equally often.
         pure = ("prestep_t3", "rhs_t3", "rhs_uv_3d", "uv_corrector", "vert_visc_3d", "prestep_uv", "uv3dmix", "rho_eos", "prsgrd", "massflux_omega")
-        red_dev = "cpu" if host_transport else f"cuda:{local}"
+        red_dev = "cpu"
 
         def local_ms(r):
             r.timeStep(); r.sync()
@@ -367,24 +451,11 @@ def main():
         placement = {"tries": len(log), "rank0_local_kernel_ms_per_step": [round(x, 2) for x in log], "kept": round(best_ms, 2),
                      "note": "per rank: state block re-allocated, judged by the rank's own non-exchanging kernel groups"}
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        rem.timeStep()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        rem.timeStep()
-    barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cpu" if host_transport else f"cuda:{local}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    if placement is not None:
+        wall["placement_search_s"] = round(time.perf_counter() - t_place, 2)
+    t_timed = time.perf_counter()
+    el = timed(rem, a.warmup, a.steps)
+    wall["timed_run_s"] = round(time.perf_counter() - t_timed, 2)
 
     # sanity: the fields must still be finite (an invalid run must not produce a number)
     chk = rem.view("cons_new")[0]
@@ -411,6 +482,10 @@ def main():
 
     if "massflux_rest" in rep:                             # the velocity corrector carried update_massflux_3d (valid non-wall faces)
         ALGO_DOUBLES["uv_corrector"] = UV_CORRECTOR_MF
+    from remora_amd import lib as L_
+    if rem.params.vmix_mode == L_.VMIX_CONST and os.environ.get("RH_VMIX_REWRITE", "0") in ("", "0"):
+        for g, less in CONST_VMIX_LESS.items():
+            ALGO_DOUBLES[g] -= less
     # k2d_fused: one CALL of the barotropic kernel is two launches (interior, rim) when the exchange runs under it; price per call
     k2d_calls = 2 * rem.nfast * nprof
     if "k2d_fused" in rep and rep["k2d_fused"]["calls"] > k2d_calls:
@@ -443,8 +518,11 @@ def main():
                  "frac_3d": (b3 / (t3 * 1e-3) / 1e9 / HBM_PEAK_GBS) if t3 > 0 else None,
                  "bytes_2d": b2, "ms_step_profiled": round(t_all, 3),
                  "frac_step": ((b3 + b2) / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBS) if t_all > 0 else None,
+                 "frac_3d_at_round2_bytes": (114.0 * 8 * cells_per_gpu / (t3 * 1e-3) / 1e9 / HBM_PEAK_GBS) if t3 > 0 else None,
                  "frac_3d_reference_granular": (1232.0 * cells_per_gpu / (t3 * 1e-3) / 1e9 / HBM_PEAK_GBS) if t3 > 0 else None,
-                 "note": "frac_3d = union bytes of the fused 3-D kernels / (setup_step + advance_3d_ml time); frac_step adds the k2d_fused bytes "
+                 "note": "frac_3d = union bytes of the fused 3-D kernels / (setup_step + advance_3d_ml time); frac_3d_at_round2_bytes prices the same time "
+                         "against the 114 doubles per cell the round-2 kernels moved algorithmically (this round removed bytes: rho / P never stored, "
+                         "constant mixing never re-read), for comparison across rounds; frac_step adds the k2d_fused bytes "
                          "and divides by the whole step; frac_3d_reference_granular prices the same time against the 1232 B/cell the "
                          "reference's own pass structure moves (SURVEY.md 8d)"}
     # the barotropic loop: its share of the step, launches per call and what a call costs outside the fused kernel (launch gaps,
@@ -458,10 +536,14 @@ def main():
         out = {"metric": "3D baroclinic cell-updates/s", "value": cells_per_gpu * world * a.steps / el, "unit": "cell-updates/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-               "config": {"workload": f"{a.case} physics, {a.nx}x{a.ny}x{nz} cells per GPU (domain {nx}x{ny}x{nz}), "
+               "config": {"workload": f"{'BASELINE configs[4]: ' if a.workload == 'config4' else ''}{a.case} physics, {a.nx}x{a.ny}x{nz} cells per GPU (domain {nx}x{ny}x{nz}), "
                                       f"dt {case['fixed_dt']:.3f} s, ndtfast {case['ndtfast']}, nfast {rem.nfast}, "
                                       f"{f'{px}x{py} i-j decomposition, ghost exchange over ' + ('gloo (host-staged)' if host_transport else 'RCCL') if world > 1 else 'single box'}",
                           "parallelism": f"ij-decomp {px}x{py}"},
+               **({"ms_per_step_first_allocation": first_alloc["ms_per_step"], "value_first_allocation": first_alloc["value"],
+                   "first_allocation_note": "same W / K on the state block as first allocated (what a caller that binds its arrays once sees); "
+                                            "`value` is timed on the block the placement search kept"} if first_alloc else {}),
+               "wall_s": dict(wall, total_s=round(time.perf_counter() - t_start, 2)),
                "finite": finite, "build": build, **({"exchange": exchange_mode} if exchange_mode else {}), **({"placement": placement} if placement else {}), **({"transport": "host-staged gloo rehearsal (NOT the RCCL configuration)"} if host_transport else {}),
                "roofline": roof, "step_roofline": step_roof, **({"barotropic_loop": baro} if baro else {}), "kernels": kern,
                "kernel_ms_per_step": {k: round(v["ms"] / nprof, 4) for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"])}}
