@@ -785,15 +785,16 @@ k_prsgrd_uv_tiled(B3 ub, B3 vb, B3 un, A4 ru, A4 rv, A4 pn, A4 pm, A4 rho, A4 P,
 // ---- rho_eos + the hydrostatic pressure + the horizontal differences of prsgrd in ONE downward march (setup_step.cpp:200 and :262-266:
 // nothing between the two calls touches their operands).  k_rho_eos_P + k_prsgrd_uv_tiled hand rho and P over through HBM (written
 // once, read 1.2-1.3 times with the halo rows) although both are column-local functions of T, S, Hz, z_r.  Here a block owns a
-// 64 x 16 tile of momentum points and marches EVERY column of the tile grown by two cells: a thread carries the column of its own
-// point and, for the first 336 threads, one column of the halo ring.  Per level a column forms rho(k) from T, S (rho_eos.cpp:54-59),
+// 64 x 11 tile of momentum points and marches EVERY column of the tile grown by two cells (68 x 15 = 1020 columns, one per thread of
+// the block's 16 wavefronts).  Per level a column forms rho(k) from T, S (rho_eos.cpp:54-59),
 // the column sums and bvf (:69-98) and prsgrd's P(k+1) one level behind (prsgrd.cpp:54-99) -- the body of k_rho_eos_P -- and puts
 // rho, z_r, Hz of level k (ring of three levels) and P(k+1) (two) into LDS; after the barrier the tile's threads form ru, rv of
 // level k+1 from LDS with k_prsgrd_uv_tiled's own expression.  rho and P never reach memory: 14 -> ~8 doubles per cell for the two
 // leaves.  Halo columns are marched once per sharing block: the same operands through the same expressions, hence the same bits.
 // bvf, rhoA, rhoS (wanted on the cell box grown by two, REMORA_setup_step.cpp:166-200) are stored by the block that owns the
 // point: the block whose tile holds the point clamped into the box of momentum points.
-#define RP_BY 16
+#define RP_BY 11       // rows of momentum points per block
+#define RP_WAVES 16    // wavefronts per block: RP_BY own the tile, the rest march the halo ring
 // what a marching column carries from level to level.  k_rho_eos_P's r_up / z_up are r_k / z_k here and its raw slopes dRraw_k / dZraw_k
 // are r_k1 - r_k / z_k1 - z_k, formed again where they are used: the same operands through the same operation, hence the same bits,
 // and four doubles fewer per column in a kernel whose threads carry two columns within 128 registers.
@@ -852,95 +853,102 @@ __device__ __forceinline__ double rp_P0(const RPState &q, const RPConst &c)     
     const double rz_avg = (q.r_k1 + q.r_k) * (q.z_k1 - q.z_k);
     return q.Pk1 + HalfGRho * (rz_avg - OneFifth * ((q.dRh_k1 - dRh_k) * z_diff - (q.dZh_k1 - dZh_k) * rho_diff));
 }
-__global__ void __launch_bounds__(RT_BX * RP_BY)
+// Block = 16 wavefronts: RP_BY = 11 of them own the tile's 64 x 11 momentum points (and march those columns), the other five march
+// the 316 columns of the halo ring -- ONE column per thread (two per thread did not fit 128 registers: 49 spilled), 1020 of 1024
+// threads busy in the march, the eleven tile waves alone in the momentum stage.
+__global__ void __launch_bounds__(RT_BX * RP_WAVES)
 k_rho_prsgrd(B3 gb, B3 ub, B3 vb, B3 un, A4 st, A4 rhoA, A4 rhoS, A4 bvf, A4 Hz, A4 z_w, A4 z_r, A4 h, A4 mskr,
              A4 ru, A4 rv, A4 pn, A4 pm, A4 msku, A4 mskv, int nrhs, int N, RPConst cst)
 {
     typedef Tile<2, 2, RP_BY> T2;
-    constexpr int SZ = T2::SIZE;
+    constexpr int SZ = T2::SIZE + 4;                        // + a spare slot: the four threads without a column park their values there
+    static_assert(T2::NHALO <= RT_BX * (RP_WAVES - RP_BY), "one halo column per thread of the halo waves");
     __shared__ double lds[13 * SZ];                         // rho, z_r, Hz: three levels each; P: two; msku, mskv
     double *const sR = lds, *const sZ = lds + 3 * SZ, *const sH = lds + 6 * SZ, *const sP = lds + 9 * SZ;
     double *const sMu = lds + 11 * SZ, *const sMv = lds + 12 * SZ;
     const int tx = threadIdx.x, ty = threadIdx.y;
     const RhTile rh_t_ = rh_tile();
     const int i0 = un.lo0 + rh_t_.x * RT_BX, j0 = un.lo1 + rh_t_.y * RP_BY;
-    const int i = i0 + tx, j = j0 + ty;
-    const double HalfGRho = 0.5 * (cst.g / cst.rho0);
-    const bool au = inb2(ub, i, j), av = inb2(vb, i, j);
-    double on_u = 0.0, om_v = 0.0;
-    if (au) on_u = 2.0 / (pn(i - 1, j, 0) + pn(i, j, 0));
-    if (av) om_v = 2.0 / (pm(i, j - 1, 0) + pm(i, j, 0));
-    // the two columns of this thread: its own point and (threads 0 .. NHALO-1) one cell of the halo ring
-    int hx = 0, hy = 0;
-    const int t = ty * RT_BX + tx;
-    const bool has1 = t < T2::NHALO;
-    if (has1) {
-        if (t < T2::NROWCELLS) { const int r = t / T2::PX; hx = t - r * T2::PX; hy = r < 2 ? r : RP_BY + r; }
-        else { const int u = t - T2::NROWCELLS; const int r = u / 4; const int xx = u - r * 4; hy = 2 + r; hx = xx < 2 ? xx : RT_BX + xx; }
+    const bool tile_wave = ty < RP_BY;                      // wave-uniform
+    // this thread's column: its own point (tile waves) or one cell of the halo ring (halo waves)
+    int x, y;                                               // position inside the grown tile
+    bool has = true;
+    if (tile_wave) { x = tx + 2; y = ty + 2; }
+    else {
+        const int t = (ty - RP_BY) * RT_BX + tx;
+        has = t < T2::NHALO;
+        x = 0; y = 0;
+        if (has) {
+            if (t < T2::NROWCELLS) { const int r = t / T2::PX; x = t - r * T2::PX; y = r < 2 ? r : RP_BY + r; }
+            else { const int u = t - T2::NROWCELLS; const int r = u / 4; const int xx = u - r * 4; y = 2 + r; x = xx < 2 ? xx : RT_BX + xx; }
+        }
     }
-    const int gi1 = i0 - 2 + hx, gj1 = j0 - 2 + hy;
-    const int l0 = (ty + 2) * T2::PX + (tx + 2), l1 = hy * T2::PX + hx;
-    const bool act0 = inb2(gb, i, j), act1 = has1 && inb2(gb, gi1, gj1);
+    const int gi = i0 - 2 + x, gj = j0 - 2 + y;             // the column's cell
+    // every thread marches: no branch around the loads (at a join of paths with different numbers of loads in flight hipcc waits for
+    // ALL of them, vmcnt(0), and the two-level prefetch below would be drained at every level)
+    const int l0 = has ? y * T2::PX + x : T2::SIZE;
+    const double HalfGRho = 0.5 * (cst.g / cst.rho0);
+    const bool au = tile_wave && inb2(ub, gi, gj), av = tile_wave && inb2(vb, gi, gj);
+    double on_u = 0.0, om_v = 0.0;
+    if (au) on_u = 2.0 / (pn(gi - 1, gj, 0) + pn(gi, gj, 0));
+    if (av) om_v = 2.0 / (pm(gi, gj - 1, 0) + pm(gi, gj, 0));
+    const bool act = has && inb2(gb, gi, gj);
     // loads of a column that is not wanted go to a point that exists (its values are never used)
-    const int ci0 = min(max(i, gb.lo0), gb.hi0), cj0 = min(max(j, gb.lo1), gb.hi1);
-    const int ci1 = min(max(gi1, gb.lo0), gb.hi0), cj1 = min(max(gj1, gb.lo1), gb.hi1);
-    auto owner = [&](int gi, int gj) -> bool {
+    const int ci = min(max(gi, gb.lo0), gb.hi0), cj = min(max(gj, gb.lo1), gb.hi1);
+    bool own;
+    {   // the block that stores bvf / rhoA / rhoS of a cell: the one whose tile holds the cell clamped into the box of momentum points
         const int qi = min(max(gi, un.lo0), un.hi0), qj = min(max(gj, un.lo1), un.hi1);
-        return qi >= i0 && qi < i0 + RT_BX && qj >= j0 && qj < j0 + RP_BY;
-    };
-    const bool own0 = act0 && owner(i, j), own1 = act1 && owner(gi1, gj1);
+        own = act && qi >= i0 && qi < i0 + RT_BX && qj >= j0 && qj < j0 + RP_BY;
+    }
     // the velocity masks of the tile, staged once (the momentum points read them at i-1 .. i+1 / j-1 .. j+1 at every level)
-    auto m_in = [&](const A4 &a, int gi, int gj) -> double { return (gi >= a.lo0 && gi <= a.hi0 && gj >= a.lo1 && gj <= a.hi1) ? a(gi, gj, 0) : 0.0; };
-    sMu[l0] = m_in(msku, i, j); sMv[l0] = m_in(mskv, i, j);
-    if (has1) { sMu[l1] = m_in(msku, gi1, gj1); sMv[l1] = m_in(mskv, gi1, gj1); }
-    const double m0 = mskr(ci0, cj0, 0);
-    double m1 = 0.0;
-    if (has1) m1 = mskr(ci1, cj1, 0);
-    const unsigned oW0 = z_w.ix(ci0, cj0, N + 1), oW1 = z_w.ix(ci1, cj1, N + 1);
-    auto zw0 = [&]() -> double { return z_w.p[oW0]; };
-    auto zw1 = [&]() -> double { return z_w.p[oW1]; };
-    unsigned oT0 = st.ix(ci0, cj0, N), oH0 = Hz.ix(ci0, cj0, N), oZ0 = z_r.ix(ci0, cj0, N);
-    unsigned oT1 = st.ix(ci1, cj1, N), oH1 = Hz.ix(ci1, cj1, N), oZ1 = z_r.ix(ci1, cj1, N);
-    RPState q0, q1;
-    q0.A = q0.S = q0.dRh_k1 = q0.dZh_k1 = q0.r_k1 = q0.z_k1 = q0.r_k = q0.z_k = q0.Pk1 = 0.0;
-    q1 = q0;
-    double t0 = st.p[oT0], s0 = st.p[oT0 + st.sn], h0 = Hz.p[oH0], z0 = z_r.p[oZ0];
-    double t1 = 0.0, s1 = 0.0, h1 = 0.0, z1 = 0.0;
-    if (has1) { t1 = st.p[oT1]; s1 = st.p[oT1 + st.sn]; h1 = Hz.p[oH1]; z1 = z_r.p[oZ1]; }
+    auto m_in = [&](const A4 &a) -> double { return (gi >= a.lo0 && gi <= a.hi0 && gj >= a.lo1 && gj <= a.hi1) ? a(gi, gj, 0) : 0.0; };
+    sMu[l0] = m_in(msku); sMv[l0] = m_in(mskv);
+    const double m0 = mskr(ci, cj, 0);
+    const unsigned oW = z_w.ix(ci, cj, N + 1);
+    auto zw = [&]() -> double { return z_w.p[oW]; };
+    RPState q;
+    q.A = q.S = q.dRh_k1 = q.dZh_k1 = q.r_k1 = q.z_k1 = q.r_k = q.z_k = q.Pk1 = 0.0;
+    // operands of a level: requested TWO levels ahead (two register sets, the loop unrolled by two so that no copy ties a set to the
+    // wait of the other: the wave waits for the older level only).  One level ahead left the waves parked on memory two thirds of
+    // their cycles (PMC, profiles/r3_*_sq_counters.txt): the momentum stage of one level is shorter than a loaded memory round trip.
+    struct Lvl { double t, s, h, z; };
+    const unsigned oT = st.ix(ci, cj, 0), oH = Hz.ix(ci, cj, 0), oZ = z_r.ix(ci, cj, 0);
+    auto load = [&](int k) -> Lvl {
+        const unsigned kk = (unsigned)(k > 0 ? k : 0);
+        Lvl v; v.t = st.p[oT + kk * st.sz]; v.s = st.p[oT + kk * st.sz + st.sn]; v.h = Hz.p[oH + kk * Hz.sz]; v.z = z_r.p[oZ + kk * z_r.sz]; return v;
+    };
     auto momentum = [&](int kk) {                            // ru, rv of level kk from the staged tiles (k_prsgrd_uv_tiled)
         const int r3 = kk % 3;
         const TView<2, 2, RP_BY> vr{sR + r3 * SZ, i0, j0}, vz{sZ + r3 * SZ, i0, j0}, vh{sH + r3 * SZ, i0, j0}, vp{sP + (kk & 1) * SZ, i0, j0};
-        if (au) ru(i, j, kk, nrhs) = prsgrd_point(vr, vz, vp, vh, i, j, kk, 1, 0, sMu[l0 - 1], sMu[l0], sMu[l0 + 1], on_u, HalfGRho);
-        if (av) rv(i, j, kk, nrhs) = prsgrd_point(vr, vz, vp, vh, i, j, kk, 0, 1, sMv[l0 - T2::PX], sMv[l0], sMv[l0 + T2::PX], om_v, HalfGRho);
+        if (au) ru(gi, gj, kk, nrhs) = prsgrd_point(vr, vz, vp, vh, gi, gj, kk, 1, 0, sMu[l0 - 1], sMu[l0], sMu[l0 + 1], on_u, HalfGRho);
+        if (av) rv(gi, gj, kk, nrhs) = prsgrd_point(vr, vz, vp, vh, gi, gj, kk, 0, 1, sMv[l0 - T2::PX], sMv[l0], sMv[l0 + T2::PX], om_v, HalfGRho);
     };
-    for (int k = N; k >= 0; k--) {
+    auto level = [&](int k, const Lvl &v) {
         const int r3 = k % 3;
-        double *const pr = sR + r3 * SZ, *const pz = sZ + r3 * SZ, *const ph = sH + r3 * SZ, *const pp = sP + ((k + 1) & 1) * SZ;
         double Pn = 0.0;
-        const double ra = rp_level(q0, k, N, t0, s0, h0, z0, m0, zw0, own0, bvf, i, j, cst, Pn);
-        pr[l0] = ra; pz[l0] = z0; ph[l0] = h0; if (k < N) pp[l0] = Pn;
-        if (k > 0) { oT0 -= st.sz; oH0 -= Hz.sz; oZ0 -= z_r.sz; t0 = st.p[oT0]; s0 = st.p[oT0 + st.sn]; h0 = Hz.p[oH0]; z0 = z_r.p[oZ0]; }
-        if (has1) {
-            double Pm = 0.0;
-            const double rb = rp_level(q1, k, N, t1, s1, h1, z1, m1, zw1, own1, bvf, gi1, gj1, cst, Pm);
-            pr[l1] = rb; pz[l1] = z1; ph[l1] = h1; if (k < N) pp[l1] = Pm;
-            if (k > 0) { oT1 -= st.sz; oH1 -= Hz.sz; oZ1 -= z_r.sz; t1 = st.p[oT1]; s1 = st.p[oT1 + st.sn]; h1 = Hz.p[oH1]; z1 = z_r.p[oZ1]; }
-        }
+        const double ra = rp_level(q, k, N, v.t, v.s, v.h, v.z, m0, zw, own, bvf, gi, gj, cst, Pn);
+        sR[r3 * SZ + l0] = ra; sZ[r3 * SZ + l0] = v.z; sH[r3 * SZ + l0] = v.h; if (k < N) sP[((k + 1) & 1) * SZ + l0] = Pn;
+    };
+    Lvl a = load(N), b = load(N - 1);
+    for (int k = N; k >= 0; k -= 2) {
+        level(k, a);
+        a = load(k - 2);
         __syncthreads();
-        if (k < N) momentum(k + 1);
+        if (tile_wave && k < N) momentum(k + 1);
+        if (k - 1 >= 0) {
+            level(k - 1, b);
+            b = load(k - 3);
+            __syncthreads();
+            if (tile_wave) momentum(k);
+        }
     }
-    sP[l0] = rp_P0(q0, cst);
-    if (has1) sP[l1] = rp_P0(q1, cst);
+    sP[l0] = rp_P0(q, cst);
     __syncthreads();
-    momentum(0);
-    const double cff2 = 1.0 / cst.rho0;
-    if (own0) {
-        const double cff11 = 1.0 / (zw0() + h(i, j, 0, 0));
-        rhoA(i, j, 0) = q0.A * (cff2 * cff11); rhoS(i, j, 0) = q0.S * (2.0 * cff11 * cff11 * cff2);
-    }
-    if (own1) {
-        const double cff11 = 1.0 / (zw1() + h(gi1, gj1, 0, 0));
-        rhoA(gi1, gj1, 0) = q1.A * (cff2 * cff11); rhoS(gi1, gj1, 0) = q1.S * (2.0 * cff11 * cff11 * cff2);
+    if (tile_wave) momentum(0);
+    if (own) {
+        const double cff2 = 1.0 / cst.rho0;
+        const double cff11 = 1.0 / (zw() + h(gi, gj, 0, 0));
+        rhoA(gi, gj, 0) = q.A * (cff2 * cff11); rhoS(gi, gj, 0) = q.S * (2.0 * cff11 * cff11 * cff2);
     }
 }
 // setup_step's rho_eos (:200) and prsgrd (:262-266) as the one launch above; *applied = 0 when the form does not apply
@@ -967,7 +975,7 @@ int launch_rho_prsgrd(rh_ctx *c, rh_state *s, rh_box gbx2, rh_box xbx, rh_box yb
     const rh_params &P = c->prm;
     const RPConst cst{P.R0, P.S0, P.T0, P.Tcoef, P.Scoef, P.rho0, P.g};
     const dim3 pg((un.hi[0] - un.lo[0] + RT_BX) / RT_BX, (un.hi[1] - un.lo[1] + RP_BY) / RP_BY, 1);
-    k_rho_prsgrd<<<pg, dim3(RT_BX, RP_BY, 1), 0, c->stream>>>(mkB(gbx2), mkB(xbx), mkB(ybx), mkB(un), mkA(s->cons_old), mkA(s->rhoA), mkA(s->rhoS),
+    k_rho_prsgrd<<<pg, dim3(RT_BX, RP_WAVES, 1), 0, c->stream>>>(mkB(gbx2), mkB(xbx), mkB(ybx), mkB(un), mkA(s->cons_old), mkA(s->rhoA), mkA(s->rhoS),
         mkA(s->bvf), mkA(s->Hz), mkA(s->z_w), mkA(s->z_r), mkA(s->h), mkA(s->mskr), mkA(s->ru), mkA(s->rv), mkA(s->pn), mkA(s->pm), mkA(s->msku),
         mkA(s->mskv), nrhs, N, cst);
     RH_LAUNCH_CHECK();
