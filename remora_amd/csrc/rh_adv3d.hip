@@ -348,9 +348,14 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
                     MfTail mf)
 {
     constexpr int N = NZ - 1, VV_NZMAX = NZ;
+    // ONE array in LDS (the field the solve starts from / ends with, [k][lane]); cf, dc and the face thickness Hzk (tracers: its
+    // reciprocal, the same quotient the way up formed) in registers; the
+    // face-averaged mixing coefficient is read again on the way down (one more operand per level, in a ring of its own -- a constant
+    // row under RH_VMIX_CONST).  With Hzk in LDS as well (round 2) a wave needed 2 x NZ x 512 B = 51 KB at 50 levels, 65 KB at 64:
+    // three, respectively two, of the CU's four SIMDs had a wave (each wave owns its SIMD's whole register file); now all four do.
     extern __shared__ double vv_lds[];
     const int lane = threadIdx.x;
-    double *sX = vv_lds + lane, *sH = vv_lds + (size_t)(N + 1) * 64 + lane;        // s[k * 64], k = 0 .. N
+    double *sX = vv_lds + lane;                                                     // s[k * 64], k = 0 .. N
     constexpr int SX = IO ? 63 : 64;
     const RhTile rh_t_ = JO ? rh_tile_patch<1, 4>() : rh_tile();
     const int i = bx.lo0 - IO + rh_t_.x * SX + lane, j = bx.lo1 + rh_t_.y;
@@ -376,7 +381,7 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
         ColLvl v; v.P = phi(ip, j, kc); v.R = FULL ? rphi(ip, j, kc) : 0.0; v.H = Hz(ic, j, kc); v.Hx = ld2(Hz, kc);
         v.A = Akv(ic, j, kc + 1); v.Ax = ld2(Akv, kc + 1); return v;
     };
-    double cf[VV_NZMAX], dc[VV_NZMAX], ak[VV_NZMAX];
+    double cf[VV_NZMAX], dc[VV_NZMAX], hzk[VV_NZMAX];
     double Hzk_m, AK_m, AK_0, phi_m;
     {
         const double h = Hz(ic, j, 0), hx = ld2(Hz, 0), a0 = Akv(ic, j, 0), a0x = ld2(Akv, 0), a1 = Akv(ic, j, 1), a1x = ld2(Akv, 1);
@@ -386,9 +391,9 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
         AK_0 = 0.5 * (second(a1, a1x) + a1);
         phi_m = start(phi(ip, j, 0), FULL ? rphi(ip, j, 0) : 0.0, hs);
     }
-    ak[0] = AK_m; cf[0] = 0.0; dc[0] = 0.0;
-    sX[0] = phi_m; sH[0] = Hzk_m;
     double CFp = 0.0, DCp = 0.0, oHz_m = 1.0 / Hzk_m;
+    cf[0] = 0.0; dc[0] = 0.0; hzk[0] = FULL ? Hzk_m : oHz_m;
+    sX[0] = phi_m;
     ColLvl ring[D];
 #pragma unroll
     for (int u = 0; u < D; u++) ring[u] = load_f(1 + u);
@@ -409,43 +414,58 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
         const double cff = 1.0 / (BC - FC * CFp);
         CF *= cff;
         const double DC = cff * (phi_0 - phi_m - FC * DCp);
-        cf[k] = CF; dc[k] = DC; ak[k] = AK_0;
-        sX[k * 64] = phi_0; sH[k * 64] = Hzk_0;
+        cf[k] = CF; dc[k] = DC; hzk[k] = FULL ? Hzk_0 : oHz;      // tracers only ever need the reciprocal again
+        sX[k * 64] = phi_0;
         __builtin_amdgcn_sched_barrier(0);
         ring[(k - 1) % D] = load_f(k + D);
         double carry = phi_0; asm volatile("" : "+v"(carry));
         CFp = CF; DCp = DC; Hzk_m = Hzk_0; AK_m = AK_0; AK_0 = AK_p; phi_m = carry; oHz_m = oHz;
         }
     }
-    // ---- back-substitution fused with the update, :81-106.  Here AK_0 = AK(N+1).  No global loads.
+    // ---- back-substitution fused with the update, :81-106.  Here AK_0 = AK(N+1).  The only global loads are the mixing
+    // coefficients of the level (the same operands the way up averaged, through the same expression: the same AK(k)), DB levels ahead.
+    constexpr int DB = NZ > 50 ? 4 : 12;
+    struct AkL { double A, Ax; };
+    auto load_a = [&](int k) -> AkL { const int kc = k > 0 ? k : 0; AkL v; v.A = Akv(ic, j, kc); v.Ax = ld2(Akv, kc); return v; };
+    AkL aring[DB];
+#pragma unroll
+    for (int u = 0; u < DB; u++) aring[u] = load_a(N - u);
     double DC_up = 0.0, DCs_up = DC_up * AK_0;
 #pragma clang loop unroll(full)
     for (int k = VV_NZMAX - 1; k >= 0; k--) {
         {
+            const AkL a = aring[(N - k) % DB];
+            const double AKk = 0.5 * (second(a.A, a.Ax) + a.A);
             double DC;
             if (k >= 1) { DC = dc[k]; DC -= cf[k] * DC_up; }
             else DC = 0.0;
-            const double DCs = DC * ak[k];
-            const double Hzk = sH[k * 64];
-            const double oHz = 1.0 / Hzk;
+            const double DCs = DC * AKk;
+            // FULL: the thickness itself is kept (the depth mean needs it) and its reciprocal is formed again here -- through an opaque
+            // move, or hipcc recognises the quotient of the way up and keeps all NZ of them alive instead (100-128 more registers)
+            double Hzk = hzk[k];
+            if (FULL) asm volatile("" : "+v"(Hzk));
+            const double oHz = FULL ? 1.0 / Hzk : Hzk;
             const double cff = dt * oHz * (DCs_up - DCs);
             const double x = sX[k * 64] + cff;
             if (FULL) sX[k * 64] = x;
             else if (act) phi(i, j, k) = x;
+            __builtin_amdgcn_sched_barrier(0);
+            aring[(N - k) % DB] = load_a(k - DB);
             DC_up = DC; DCs_up = DCs;
         }
     }
     if (!FULL) return;
     // the old mass flux of the fused update_massflux_3d tail is requested here, while the depth mean is being summed
-    constexpr int MD = NZ > 50 ? 12 : 20;
+    constexpr int MD = NZ > 50 ? 6 : 20;
     double hq[MD];
     if (mf.on) {
 #pragma unroll
         for (int u = 0; u < MD; u++) hq[u] = mf.Hphi(ip, j, u < N ? u : N);
     }
     // ---- vert_mean_3d: ascending sums in the reference's order (:22-34), then the correction (:36-46)
-    double CF = sH[0], DCm = sX[0] * CF;
-    for (int k = 1; k <= N; k++) { const double Hzf = sH[k * 64]; CF += Hzf; DCm += sX[k * 64] * Hzf; }
+    double CF = hzk[0], DCm = sX[0] * CF;
+#pragma clang loop unroll(full)
+    for (int k = 1; k <= N; k++) { const double Hzf = hzk[k]; CF += Hzf; DCm += sX[k * 64] * Hzf; }
     const double on = 2.0 / (dxlen(ip - IO, jj, 0) + dxlen(ip, j, 0));
     const double cff1 = 1.0 / (CF * (on));
     DCm = (DCm * (on) - Davg1(ip, j, 0)) * cff1;
@@ -455,10 +475,10 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
             for (int k = 0; k <= N; k++) { double x = sX[k * 64]; x -= DCm; x *= m; phi(i, j, k) = x; }
         return;
     }
-    // ---- update_massflux_3d (REMORA_update_massflux_3d.cpp:24-122) for this column while its final velocity and its layer thickness
-    // are still in LDS: Hphi = 1/2 (Hphi + phi DC) with its depth integral replaced by Davg2, phibar.  Same expressions and the same
-    // ascending sums as k_massflux_lds; DC(k) = (0.5 on) (Hz + Hz') is rebuilt from the parked Hzk = 0.5 (Hz' + Hz) (the factor 2 is
-    // exact).  Columns on a wall face are left out: the reference corrects their velocity after the physical BCs have been applied
+    // ---- update_massflux_3d (REMORA_update_massflux_3d.cpp:24-122) for this column while its final velocity is still in LDS and its
+    // layer thickness in registers: Hphi = 1/2 (Hphi + phi DC) with its depth integral replaced by Davg2, phibar.  Same expressions and
+    // the same ascending sums as k_massflux_lds; DC(k) = (0.5 on) (Hz + Hz') is rebuilt from the kept Hzk = 0.5 (Hz' + Hz) (the factor 2
+    // is exact).  Columns on a wall face are left out: the reference corrects their velocity after the physical BCs have been applied
     // to it (advance_3d.cpp:154-155, then :87-101 of update_massflux_3d), so they wait for the strips pass that follows physbc.
     const bool edge = (ip == mf.dlox - JO && !mf.perx) || (ip == mf.dhix + 1 && !mf.perx) || (j == mf.dloy - IO && !mf.pery) || (j == mf.dhiy + 1 && !mf.pery);
     const bool mfa = act && !edge;
@@ -468,7 +488,7 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
     for (int k = 0; k < VV_NZMAX; k++) {
         double x = sX[k * 64]; x -= DCm; x *= m;
         if (act) phi(i, j, k) = x;
-        const double DCk = hon * (2.0 * sH[k * 64]);
+        const double DCk = hon * (2.0 * hzk[k]);
         DCs += DCk;
         const double hp = 0.5 * (hq[k % MD] + x * DCk);
         FCm += hp;
@@ -480,7 +500,7 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
     FCm = DCi * (FCm - mf.Davg2(ip, j, 0));
     if (mfa) {
 #pragma clang loop unroll(full)
-        for (int k = 0; k < VV_NZMAX; k++) mf.Hphi(i, j, k) = sX[k * 64] - (hon * (2.0 * sH[k * 64])) * FCm;
+        for (int k = 0; k < VV_NZMAX; k++) mf.Hphi(i, j, k) = sX[k * 64] - (hon * (2.0 * hzk[k])) * FCm;
         const double pb = DCi * a1;
         mf.phibar(i, j, 0, 0) = pb; mf.phibar(i, j, 0, 1) = pb;
     }
@@ -513,7 +533,7 @@ int vert_visc_3d_view(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 ph
         const dim3 gridu((phi_bx.hi[0] - phi_bx.lo[0] + 63) / 63, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);     // u waves overlap by one column
         const A4 z = mkA(phi);                           // unused operands of the FULL form
         MfTail mfz; memset(&mfz, 0, sizeof mfz);
-        const size_t lds_reg = sizeof(double) * 2 * (size_t)(N + 1) * 64;
+        const size_t lds_reg = sizeof(double) * (size_t)(N + 1) * 64;
         if (vv_reg_depth(N + 1) && !c->noregsolve) {     // a depth the register form is built for: no operand is read twice
 #define RH_VVR(NZ) do { \
             if (ioff) k_column_solver_reg<1, 0, 0, VVD<NZ>::U, NZ><<<gridu, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0, mfz); \
@@ -552,7 +572,7 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     RH_NEED(s->DU_avg1, bx_slab(xbx, 2, 0)); RH_NEED(s->DV_avg1, bx_slab(ybx, 2, 0)); RH_NEED(s->msku, bx_slab(xbx, 2, 0)); RH_NEED(s->mskv, bx_slab(ybx, 2, 0));
     const dim3 gx((xbx.hi[0] - xbx.lo[0] + 63) / 63, xbx.hi[1] - xbx.lo[1] + 1, 1), gy((ybx.hi[0] - ybx.lo[0] + 64) / 64, ybx.hi[1] - ybx.lo[1] + 1, 1);
     const bool reg = vv_reg_depth(N + 1) && !c->noregsolve;
-    const size_t lds_reg = sizeof(double) * 2 * (size_t)(N + 1) * 64;
+    const size_t lds_reg = sizeof(double) * (size_t)(N + 1) * 64;
     // update_massflux_3d rides on the same sweep (the column's final velocity and thickness are in LDS when the corrector ends):
     // *applied = 2 tells the caller to run update_massflux_3d only on what this launch leaves out (ghost faces, wall faces)
     MfTail mfu, mfv; memset(&mfu, 0, sizeof mfu); memset(&mfv, 0, sizeof mfv);
