@@ -867,7 +867,7 @@ k_rho_prsgrd(B3 gb, B3 ub, B3 vb, B3 un, A4 st, A4 rhoA, A4 rhoS, A4 bvf, A4 Hz,
     double *const sR = lds, *const sZ = lds + 3 * SZ, *const sH = lds + 6 * SZ, *const sP = lds + 9 * SZ;
     double *const sMu = lds + 11 * SZ, *const sMv = lds + 12 * SZ;
     const int tx = threadIdx.x, ty = threadIdx.y;
-    const RhTile rh_t_ = rh_tile();
+    const RhTile rh_t_ = rh_tile_patch<8, 4>();          // one block per CU: the 32 resident on an XCD form a compact patch and share halo columns in its L2
     const int i0 = un.lo0 + rh_t_.x * RT_BX, j0 = un.lo1 + rh_t_.y * RP_BY;
     const bool tile_wave = ty < RP_BY;                      // wave-uniform
     // this thread's column: its own point (tile waves) or one cell of the halo ring (halo waves)
