@@ -342,12 +342,17 @@ struct MfTail { int on, dlox, dhix, dloy, dhiy, perx, pery; A4 Hphi, phibar, Dav
 // The number of levels is a template parameter: with a run-time trip count every unrolled level becomes a guarded block, and the
 // wait counts hipcc then places at the joins drain the load ring (measured: 1.7x slower than the ring kernel).  Instantiated for
 // the depths of the pinned cases and of the roofline configuration; any other depth takes k_column_solver.
-template <int IO, int JO, int FULL, int D, int NZ>
+// CK = 1: the mixing coefficient is ONE number, akc (RH_VMIX_CONST once the arrays hold the constants, see mkA_vmix): no load of it on
+// either sweep, and FC(k) = sixth Hzk(k-1) - dt AK / Hzk(k-1) is the value CF(k-1) had before its scaling -- the same expression on the
+// same operands, hence the same bits -- so one of the four divisions per level goes.  0.5 (akc + akc) stands where the face average
+// of two equal coefficients stood (exact).
+template <int IO, int JO, int FULL, int D, int NZ, int CK = 0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A4 pm, A4 pn, A4 msk, int /*N*/, double dt, double cab,
-                    MfTail mf)
+                    MfTail mf, double akc)
 {
     constexpr int N = NZ - 1, VV_NZMAX = NZ;
+    const double akh = 0.5 * (akc + akc);
     // ONE array in LDS (the field the solve starts from / ends with, [k][lane]); cf, dc and the face thickness Hzk (tracers: its
     // reciprocal, the same quotient the way up formed) in registers; the
     // face-averaged mixing coefficient is read again on the way down (one more operand per level, in a ring of its own -- a constant
@@ -372,26 +377,34 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
     auto ld2 = [&](const A4 &a, int k) -> double { if (JO == 1) return a(ic, jj, k); return 0.0; };
     double c2 = 0.0;
     if (FULL) c2 = cab * (pm(ip, j, 0) + pm(ip - IO, jj, 0)) * (pn(ip, j, 0) + pn(ip - IO, jj, 0));
-    auto start = [&](double u, double r, double hsum) -> double {
+    // 2 / hsum of the reference is the reciprocal of the face thickness 0.5 hsum that the elimination needs anyway: halving is exact, and
+    // a correctly rounded quotient depends on the real value of its operands' ratio alone, so 1 / (0.5 hsum) has the bits of 2 / hsum
+    auto start = [&](double u, double r, double ohz) -> double {
         if (!FULL) return u;
-        double x = u; x += c2 * r; x *= 2.0 / hsum; return x;
+        double x = u; x += c2 * r; x *= ohz; return x;
     };
     auto load_f = [&](int k) -> ColLvl {
         const int kc = k < N ? k : N;
         ColLvl v; v.P = phi(ip, j, kc); v.R = FULL ? rphi(ip, j, kc) : 0.0; v.H = Hz(ic, j, kc); v.Hx = ld2(Hz, kc);
-        v.A = Akv(ic, j, kc + 1); v.Ax = ld2(Akv, kc + 1); return v;
+        if (CK) { v.A = 0.0; v.Ax = 0.0; } else { v.A = Akv(ic, j, kc + 1); v.Ax = ld2(Akv, kc + 1); }
+        return v;
     };
     double cf[VV_NZMAX], dc[VV_NZMAX], hzk[VV_NZMAX];
     double Hzk_m, AK_m, AK_0, phi_m;
     {
-        const double h = Hz(ic, j, 0), hx = ld2(Hz, 0), a0 = Akv(ic, j, 0), a0x = ld2(Akv, 0), a1 = Akv(ic, j, 1), a1x = ld2(Akv, 1);
+        const double h = Hz(ic, j, 0), hx = ld2(Hz, 0);
         const double hs = second(h, hx) + h;
         Hzk_m = 0.5 * hs;
-        AK_m = 0.5 * (second(a0, a0x) + a0);
-        AK_0 = 0.5 * (second(a1, a1x) + a1);
-        phi_m = start(phi(ip, j, 0), FULL ? rphi(ip, j, 0) : 0.0, hs);
+        if (CK) { AK_m = akh; AK_0 = akh; }
+        else {
+            const double a0 = Akv(ic, j, 0), a0x = ld2(Akv, 0), a1 = Akv(ic, j, 1), a1x = ld2(Akv, 1);
+            AK_m = 0.5 * (second(a0, a0x) + a0);
+            AK_0 = 0.5 * (second(a1, a1x) + a1);
+        }
+        phi_m = start(phi(ip, j, 0), FULL ? rphi(ip, j, 0) : 0.0, 1.0 / Hzk_m);
     }
     double CFp = 0.0, DCp = 0.0, oHz_m = 1.0 / Hzk_m;
+    double CFraw_m = CK ? sixth * Hzk_m - dt * AK_m / Hzk_m : 0.0;       // CK: what FC(1) is
     cf[0] = 0.0; dc[0] = 0.0; hzk[0] = FULL ? Hzk_m : oHz_m;
     sX[0] = phi_m;
     ColLvl ring[D];
@@ -404,12 +417,13 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
         const ColLvl c = ring[(k - 1) % D];
         const double hs = second(c.H, c.Hx) + c.H;
         const double Hzk_0 = 0.5 * hs;
-        const double AK_p = 0.5 * (second(c.A, c.Ax) + c.A);
-        const double phi_0 = start(c.P, c.R, hs);
+        const double AK_p = CK ? akh : 0.5 * (second(c.A, c.Ax) + c.A);
         const double oHzkm1 = oHz_m;
         const double oHz = 1.0 / Hzk_0;
-        const double FC = sixth * Hzk_m - dt * AK_m / Hzk_m;
+        const double phi_0 = start(c.P, c.R, oHz);
+        const double FC = CK ? CFraw_m : sixth * Hzk_m - dt * AK_m / Hzk_m;
         double CF = sixth * Hzk_0 - dt * AK_p / Hzk_0;
+        CFraw_m = CF;
         const double BC = third * (Hzk_m + Hzk_0) + dt * AK_0 * (oHzkm1 + oHz);
         const double cff = 1.0 / (BC - FC * CFp);
         CF *= cff;
@@ -426,7 +440,7 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
     // coefficients of the level (the same operands the way up averaged, through the same expression: the same AK(k)), DB levels ahead.
     constexpr int DB = NZ > 50 ? 4 : 12;
     struct AkL { double A, Ax; };
-    auto load_a = [&](int k) -> AkL { const int kc = k > 0 ? k : 0; AkL v; v.A = Akv(ic, j, kc); v.Ax = ld2(Akv, kc); return v; };
+    auto load_a = [&](int k) -> AkL { const int kc = k > 0 ? k : 0; AkL v; if (CK) { v.A = 0.0; v.Ax = 0.0; } else { v.A = Akv(ic, j, kc); v.Ax = ld2(Akv, kc); } return v; };
     AkL aring[DB];
 #pragma unroll
     for (int u = 0; u < DB; u++) aring[u] = load_a(N - u);
@@ -435,7 +449,7 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
     for (int k = VV_NZMAX - 1; k >= 0; k--) {
         {
             const AkL a = aring[(N - k) % DB];
-            const double AKk = 0.5 * (second(a.A, a.Ax) + a.A);
+            const double AKk = CK ? akh : 0.5 * (second(a.A, a.Ax) + a.A);
             double DC;
             if (k >= 1) { DC = dc[k]; DC -= cf[k] * DC_up; }
             else DC = 0.0;
@@ -535,12 +549,16 @@ int vert_visc_3d_view(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 ph
         MfTail mfz; memset(&mfz, 0, sizeof mfz);
         const size_t lds_reg = sizeof(double) * (size_t)(N + 1) * 64;
         if (vv_reg_depth(N + 1) && !c->noregsolve) {     // a depth the register form is built for: no operand is read twice
-#define RH_VVR(NZ) do { \
-            if (ioff) k_column_solver_reg<1, 0, 0, VVD<NZ>::U, NZ><<<gridu, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0, mfz); \
-            else if (joff) k_column_solver_reg<0, 1, 0, VVD<NZ>::V, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0, mfz); \
-            else k_column_solver_reg<0, 0, 0, VVD<NZ>::T, NZ><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0, mfz); } while (0)
+            double akc = 0.0;
+            const bool ck = vmix_row_value(c, akA, &akc) && !c->no_ckonst;
+#define RH_VVR1(NZ, CK) do { \
+            if (ioff) k_column_solver_reg<1, 0, 0, VVD<NZ>::U, NZ, CK><<<gridu, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0, mfz, akc); \
+            else if (joff) k_column_solver_reg<0, 1, 0, VVD<NZ>::V, NZ, CK><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0, mfz, akc); \
+            else k_column_solver_reg<0, 0, 0, VVD<NZ>::T, NZ, CK><<<grid, 64, lds_reg, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0, mfz, akc); } while (0)
+#define RH_VVR(NZ) do { if (ck) RH_VVR1(NZ, 1); else RH_VVR1(NZ, 0); } while (0)
             switch (N + 1) { case 13: RH_VVR(13); break; case 16: RH_VVR(16); break; case 64: RH_VVR(64); break; default: RH_VVR(50); break; }
 #undef RH_VVR
+#undef RH_VVR1
         }
         else if (ioff) k_column_solver<1, 0, 0, VV_D_U><<<gridu, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0);
         else if (joff) k_column_solver<0, 1, 0, VV_D_V><<<grid, 64, lds_bytes, c->stream>>>(mkB(phi_bx), mkA(phi), z, mkA(Hz), akA, z, z, z, z, z, N, dt, 0.0);
@@ -588,10 +606,14 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
         mfu.Hphi = mkA(s->Huon); mfu.phibar = mkA(s->ubar); mfu.Davg2 = mkA(s->DU_avg2);
         mfv.Hphi = mkA(s->Hvom); mfv.phibar = mkA(s->vbar); mfv.Davg2 = mkA(s->DV_avg2);
     }
-#define RH_VVU(NZ) k_column_solver_reg<1, 0, 1, VVD<NZ>::U, NZ><<<gx, 64, lds_reg, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), akvA, mkA(s->DU_avg1), mkA(s->pn), \
-        mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab, mfu)
-#define RH_VVV(NZ) k_column_solver_reg<0, 1, 1, VVD<NZ>::V, NZ><<<gy, 64, lds_reg, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), akvA, mkA(s->DV_avg1), mkA(s->pm), \
-        mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab, mfv)
+    double akc = 0.0;
+    const bool ck = vmix_row_value(c, akvA, &akc) && !c->no_ckonst;
+#define RH_VVU1(NZ, CK) k_column_solver_reg<1, 0, 1, VVD<NZ>::U, NZ, CK><<<gx, 64, lds_reg, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), akvA, mkA(s->DU_avg1), mkA(s->pn), \
+        mkA(s->pm), mkA(s->pn), mkA(s->msku), N, dt, cab, mfu, akc)
+#define RH_VVV1(NZ, CK) k_column_solver_reg<0, 1, 1, VVD<NZ>::V, NZ, CK><<<gy, 64, lds_reg, c->stream>>>(mkB(ybx), mkA(s->yvel_new), mkA(s->rv), mkA(s->Hz), akvA, mkA(s->DV_avg1), mkA(s->pm), \
+        mkA(s->pm), mkA(s->pn), mkA(s->mskv), N, dt, cab, mfv, akc)
+#define RH_VVU(NZ) do { if (ck) RH_VVU1(NZ, 1); else RH_VVU1(NZ, 0); } while (0)
+#define RH_VVV(NZ) do { if (ck) RH_VVV1(NZ, 1); else RH_VVV1(NZ, 0); } while (0)
     { TScope t(c, "uv_corrector");
     if (reg) { switch (N + 1) { case 13: RH_VVU(13); break; case 16: RH_VVU(16); break; case 64: RH_VVU(64); break; default: RH_VVU(50); break; } }
     else k_column_solver<1, 0, 1, VV_D_U><<<gx, 64, lds_bytes, c->stream>>>(mkB(xbx), mkA(s->xvel_new), mkA(s->ru), mkA(s->Hz), akvA, mkA(s->DU_avg1), mkA(s->pn),

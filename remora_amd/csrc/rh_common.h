@@ -186,12 +186,23 @@ struct rh_ctx {
     // remember which arrays hold the constants), and the column solvers the drivers launch read the constants from four short rows
     // (d_vmixrow: Akv, Akt x 3; zero row / level strides, so every load hits L1) instead of streaming the 3-D arrays.  Same values,
     // same expressions: bit-identical.  RH_VMIX_REWRITE=1 goes back to the per-step rewrite and the array reads (A/B parity and timing).
-    double *d_vmixrow = nullptr; int vmixrow_len = 0; const double *vmix_akv_done = nullptr, *vmix_akt_done = nullptr; bool vmix_rewrite = false;
+    double *d_vmixrow = nullptr; int vmixrow_len = 0; const double *vmix_akv_done = nullptr, *vmix_akt_done = nullptr; bool vmix_rewrite = false; bool no_ckonst = false;   // RH_NO_CKONST=1: the register solvers read the constant rows instead of taking the constant as a number (A/B parity)
+   
     ~rh_ctx() { if (bcq) bc_queue_delete(bcq); if (haloq) halo_queue_delete(haloq); }
 };
 
 // view of Akv (which = 0) or of component n of Akt (which = 1 + n) for the column solvers the drivers launch: the constant rows
 // when the arrays are known to hold the constants (see rh_ctx::d_vmixrow), the arrays themselves otherwise
+// the number a constant-row view of mkA_vmix stands for (false: `a` is a real array)
+static inline bool vmix_row_value(const rh_ctx *c, const A4 &a, double *v)
+{
+    if (!c->d_vmixrow || c->vmixrow_len <= 0 || a.sz != 0 || a.sy != 0) return false;
+    const long off = a.p - c->d_vmixrow;
+    if (off < 0 || off >= 4L * c->vmixrow_len) return false;
+    const int which = (int)(off / c->vmixrow_len);
+    *v = which == 0 ? c->prm.Akv_const : c->prm.Akt_const[which - 1];
+    return true;
+}
 static inline A4 mkA_vmix(const rh_ctx *c, const rh_state *s, int which)
 {
     const rh_array4 &real = which == 0 ? s->Akv : s->Akt;

@@ -4,6 +4,8 @@
   stream), RH_NO_BC2D=1 (ghost cells of the barotropic step through the batched BC passes instead of the rim blocks of k2d_fused) and RH_NO_MFFUSE=1 (update_massflux_3d as its own launches instead of on the velocity corrector's sweep) must give the same bits as the default path: each is checked against the oracle on the bit-exact cases.
 * RH_VMIX_REWRITE=1: constant vertical mixing rewritten at every step and read from the arrays by the column solvers (the default
   writes Akv / Akt once per bound state and gives the solvers the constants in four L1-resident rows).
+* RH_NO_CKONST=1: under constant mixing the register solvers read the constant rows like any array instead of taking the constant as
+  a number (the default drops the coefficient loads and one division per level: FC(k) is CF(k-1) before its scaling, bit for bit).
 * RH_NO_RHOFUSE=1: rho_eos (+ the hydrostatic pressure) and prsgrd as two launches with rho and P in memory (the default marches them as
   one kernel, k_rho_prsgrd, and keeps both in LDS).
 * RH_POISON=1 fills the library's work arrays with NaN at the top of every step: a kernel that read scratch it had not written
@@ -44,7 +46,7 @@ def _phases(cfg, nsteps, what):
     rem.close(); orc.close()
 
 
-@pytest.mark.parametrize("switch", ["RH_NOFUSE2D", "RH_NOREGSOLVE", "RH_POISON", "RH_NO_ASYNC", "RH_NO_BC2D", "RH_NO_MFFUSE", "RH_VMIX_REWRITE", "RH_NO_RHOFUSE"])
+@pytest.mark.parametrize("switch", ["RH_NOFUSE2D", "RH_NOREGSOLVE", "RH_POISON", "RH_NO_ASYNC", "RH_NO_BC2D", "RH_NO_MFFUSE", "RH_VMIX_REWRITE", "RH_NO_RHOFUSE", "RH_NO_CKONST"])
 @pytest.mark.parametrize("case", ["Seamount", "DoubleGyre"])
 def test_switch_keeps_the_bits(switch, case, monkeypatch):
     monkeypatch.setenv(switch, "1")
