@@ -84,6 +84,44 @@ k_stretch(B3 b, A4 z_w, A4 z_r, A4 Hz, A4 h, A4 Zt, const double *__restrict__ s
         }
     }
 }
+// The same when all five arrays are dense over exactly the box (the native state, and REMORA's MultiFabs with their 3 ghost cells): a
+// column is an index into the plane, so the launch is linear over the plane (256 columns per block, whatever the row length), the level
+// chunk is blockIdx.y, and the stretching curves are scalar loads (k is uniform over the block).  tools/ubench/stores.hip measures
+// what this access pattern stores at (profiles/r3_ubench_stores.txt: 1.09 ms for the three arrays; the tiled form above took 1.57).
+__global__ void __launch_bounds__(256)
+k_stretch_flat(double *__restrict__ z_w, double *__restrict__ z_r, double *__restrict__ Hz, double *__restrict__ h, const double *__restrict__ Zt,
+               const double *__restrict__ sc, int nxy, int nz, double hc)
+{
+    const int col = blockIdx.x * 256 + (int)threadIdx.x;
+    if (col >= nxy) return;
+    const int k0 = blockIdx.y * ST_KC;
+    const double hwater = h[col], zt = Zt[col];
+    const double *sc_w = sc, *Cs_w = sc + (nz + 1), *sc_r = sc + 2 * (nz + 1), *Cs_r = sc + 3 * (nz + 1);
+    const double hinv = 1.0 / (hc + hwater);
+    auto zw_at = [&](int k) -> double {
+        if (k == nz) return zt;
+        const double cff_w = hc * sc_w[k], cff1_w = Cs_w[k];
+        const double cff2_w = (cff_w + cff1_w * hwater) * hinv;
+        return zt + (zt + hwater) * cff2_w;
+    };
+    double zw = zw_at(k0);
+#pragma unroll
+    for (int q = 0; q < ST_KC; q++) {
+        const int k = k0 + q;
+        if (k > nz) break;
+        const size_t o = (size_t)k * nxy + col;
+        if (k == 0) h[(size_t)nxy + col] = zw;
+        z_w[o] = zw;
+        if (k != nz) {
+            const double cff_r = hc * sc_r[k], cff1_r = Cs_r[k];
+            const double cff2_r = (cff_r + cff1_r * hwater) * hinv;
+            z_r[o] = zt + (zt + hwater) * cff2_r;
+            const double zw_up = zw_at(k + 1);
+            Hz[o] = zw_up - zw;
+            zw = zw_up;
+        }
+    }
+}
 extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
 {
     TScope t(c, "stretch_transform");
@@ -94,8 +132,17 @@ extern "C" int rh_stretch_transform(rh_ctx *c, rh_state *s)
     RH_NEED(s->z_w, bw); RH_NEED(s->z_r, b); RH_NEED(s->Hz, b); RH_NEED(s->h, b2); RH_NEED(s->Zt_avg1, b2);
     if (s->h.ncomp < 2) return rh_fail("rh_stretch_transform: h needs 2 components");
     const double hc = -std::min(c->prm.prob_hi[2], -c->prm.tcline);                          // :51
-    dim3 gs = grid2(b); gs.z = (unsigned)((nz + 1 + ST_KC - 1) / ST_KC);
-    k_stretch<<<gs, rh_block(), 0, c->stream>>>(mkB(b), mkA(s->z_w), mkA(s->z_r), mkA(s->Hz), mkA(s->h), mkA(s->Zt_avg1), c->d_sc, nz, hc);
+    auto dense_on = [&](const rh_array4 &a, int klo, int khi) {
+        return a.lo[0] == b.lo[0] && a.hi[0] == b.hi[0] && a.lo[1] == b.lo[1] && a.hi[1] == b.hi[1] && a.lo[2] == klo && a.hi[2] == khi; };
+    const long nxy = (long)(b.hi[0] - b.lo[0] + 1) * (b.hi[1] - b.lo[1] + 1);
+    if (!c->unfused && !c->no_flatstretch && dense_on(s->z_w, 0, nz) && dense_on(s->z_r, 0, nz - 1) && dense_on(s->Hz, 0, nz - 1) && dense_on(s->h, 0, 0) &&
+        dense_on(s->Zt_avg1, 0, 0) && nxy * (nz + 1) < (1L << 31)) {
+        const dim3 gf((unsigned)((nxy + 255) / 256), (unsigned)((nz + 1 + ST_KC - 1) / ST_KC), 1);
+        k_stretch_flat<<<gf, 256, 0, c->stream>>>(s->z_w.p, s->z_r.p, s->Hz.p, s->h.p, s->Zt_avg1.p, c->d_sc, (int)nxy, nz, hc);
+    } else {
+        dim3 gs = grid2(b); gs.z = (unsigned)((nz + 1 + ST_KC - 1) / ST_KC);
+        k_stretch<<<gs, rh_block(), 0, c->stream>>>(mkB(b), mkA(s->z_w), mkA(s->z_r), mkA(s->Hz), mkA(s->h), mkA(s->Zt_avg1), c->d_sc, nz, hc);
+    }
     RH_LAUNCH_CHECK();
     BcScope xs(c);                                                                           // one message per neighbour for the three
     RH_TRY(halo_fill_boundary(c, mfv(c, s->z_w, 0, 0, 1), 0, 1));                            // :198-201
