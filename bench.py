@@ -77,7 +77,7 @@ GROUP_KERNELS = {
     "prestep_t3": ["k_tracers_tiled<0"], "rhs_t3": ["k_tracers_tiled<1"], "rhs_uv_3d": ["k_rhs_uv_tiled"], "uv3dmix": ["k_uv3dmix_tiled"],
     "uv_corrector": ["k_column_solver_reg<1, 0, 1", "k_column_solver_reg<0, 1, 1"], "vert_visc_3d": ["k_column_solver_reg<0, 0, 0"],
     "update_massflux_3d": ["k_massflux_lds"], "massflux_omega_new": ["k_massflux_omega_new"], "prsgrd": ["k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos_P"], "rho_prsgrd": ["k_rho_prsgrd"],
-    "omega": ["k_omega_lds"], "massflux_omega": ["k_massflux_omega<"], "prestep_uv": ["k_prestep_uv2"], "stretch_transform": ["k_stretch"],
+    "omega": ["k_omega_lds"], "massflux_omega": ["k_massflux_omega<"], "prestep_uv": ["k_prestep_uv2"], "stretch_transform": ["k_stretch_flat", "k_stretch"],
     "vmix": ["k_vmix"], "massflux_old": ["k_massflux_old"], "k2d_fused": ["k2d_fused"],
 }
 

@@ -39,6 +39,12 @@ enum { RH_BCV_CONS = 0, RH_BCV_XVEL = 3, RH_BCV_YVEL, RH_BCV_ZVEL, RH_BCV_UBAR, 
        RH_BCV_FOEXTRAP_PERIODIC, RH_BCV_FOEXTRAP, RH_BCV_U2D_SIMPLE, RH_BCV_V2D_SIMPLE, RH_BCV_NUM };
 /* analytic vertical mixing profiles = the init_custom_vmix hooks of Exec/<case>/prob.cpp that set_analytical_vmix
  * (Source/REMORA.cpp:565-573) calls from setup_step every step */
+/* RH_VMIX_CONST: the reference rewrites the same constants into Akv / Akt at every step.  Here the drivers (rh_setup_step,
+ * rh_advance) write them into the bound Akv / Akt once -- at the first step after rh_state_bind, rh_init_state or rh_read_checkpoint --
+ * and from then on give the column solvers the constants themselves instead of the arrays: in this mode the library owns the contents
+ * of Akv / Akt from that first step on; a caller that writes other values into them must bind the state again (or run with
+ * RH_VMIX_REWRITE=1: the reference's per-step rewrite and array reads).  The leaf entry point rh_vert_visc_3d always reads the
+ * array it is given. */
 enum { RH_VMIX_CONST = 0, RH_VMIX_UPWELLING = 1,
        RH_VMIX_GLS = 2 };   /* remora.vertical_mixing_type = gls: Akv / Akt come from the closure (rh_gls_*), not from a profile */
 /* remora.gls_stability_type, Source/REMORA_DataStruct.H:206-224 */

@@ -12,6 +12,9 @@ st = {}
 for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv")):
     st[r["Name"].split("(")[0].replace("void ", "")] = (int(r["Calls"]), float(r["AverageNs"]) / 1e6)
 bench.ALGO_DOUBLES["uv_corrector"] = bench.UV_CORRECTOR_MF
+if st.get("k_vmix", (9, 0))[0] <= 1:                             # constant mixing written once: the solvers do not read the arrays (bench.py does the same)
+    for g, less in bench.CONST_VMIX_LESS.items():
+        bench.ALGO_DOUBLES[g] -= less
 rows = []
 for g, pres in bench.GROUP_KERNELS.items():
     ks = [k for k in st if any(k.startswith(p) for p in pres)]
