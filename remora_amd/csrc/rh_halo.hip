@@ -497,6 +497,16 @@ static int bc_pass(rh_ctx *c, const rh_array4 &dest, int comp, rh_box r, int mod
             if (bx_ok(bx_and(r, gl)) && (r.lo[nd] != r.hi[nd])) return rh_fail("bc_pass: in-place radiation pass covers its own G line");
         } else if (bc_pending_on(c, ca.p, a4_size(ca))) RH_TRY(bc_flush(c));
     }
+    // the other direction: a queued radiation pass READS a calc array that is not its destination; a pass that writes into that array
+    // must not share its launch level (the level loop below only orders passes on one destination).  No call site of the drivers does
+    // this (calc is always an *_old array nobody fills in the same scope); the queue is flushed first if one ever does.
+    {
+        std::vector<BcPending> &Q0 = *(std::vector<BcPending> *)c->bcq;
+        const double *lo = dest.p, *hi = dest.p + a4_size(dest);
+        bool clash = false;
+        for (const BcPending &o : Q0) if (o.q.calc && o.q.calc != o.q.d && o.q.calc >= lo && o.q.calc < hi) { clash = true; break; }
+        if (clash) RH_TRY(bc_flush(c));
+    }
     std::vector<BcPending> &Q = *(std::vector<BcPending> *)c->bcq;
     p.level = 0;
     for (const BcPending &o : Q) {
