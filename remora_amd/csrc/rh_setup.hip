@@ -1255,7 +1255,19 @@ __device__ __forceinline__ double win_FCw(double qm1, double q0, double qp1, dou
     if (kk == N) return (cff1 * (q0 + qp1) - cff2 * (qm1 + qp1)) * wpart;       // q(N-1)+q(N), q(N-2)+q(N)
     return (cff1 * (q0 + qp1) - cff2 * (q0 + qp2)) * wpart;                      // kk == 1: q(0)+q(1), q(0)+q(2)
 }
-template <int C2>
+// SH = 1: the two fluxes through faces normal to x are evaluated ONCE.  UFx of the rho point west of a u point and VFx of the psi point
+// of a v point are what a lane forms; the ones east of it are its neighbour lane's (a DPP wave shift: no LDS traffic), so a thread
+// evaluates six fluxes instead of eight and reads 14 LDS operands fewer per level.  Lane 63 has no eastern neighbour: tiles advance by
+// 63 columns and its point belongs to the next tile (for the 2049 faces of the bench box that is 33 tile columns either way).
+// The shifted value is the same function of the same operands the lane would have evaluated itself: bit-identical.
+__device__ __forceinline__ double from_east_lane(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xF, 0xF, false);      // wave_shl:1 -- lane l takes lane l + 1's value
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <int C2, int SH>
 __global__ void __launch_bounds__(RT_BX * RT_BY, 2)
 k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4 rvfrc, A4 sustr, A4 svstr, A4 bustr, A4 bvstr,
                A4 Huon, A4 Hvom, A4 pm, A4 pn, A4 W, A4 Hz, A4 fcor, int use_cor, int nrhs, int N, UVGeom g)
@@ -1266,9 +1278,10 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
     const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * RT_BX + tx;
     double *inv = lds + 2 * SET + tid;
     const RhTile rh_t_ = rh_tile_patch<8, 4>();          // one block per CU (109 KB LDS): 32 resident per XCD
-    const int i0 = un.lo0 + rh_t_.x * RT_BX, j0 = un.lo1 + rh_t_.y * RT_BY;
+    const int i0 = un.lo0 + rh_t_.x * (SH ? RT_BX - 1 : RT_BX), j0 = un.lo1 + rh_t_.y * RT_BY;
     const int i = i0 + tx, j = j0 + ty;
-    const bool au = inb2(xb, i, j), av = inb2(yb, i, j);
+    const bool mine = !SH || tx < RT_BX - 1;
+    const bool au = mine && inb2(xb, i, j), av = mine && inb2(yb, i, j);
     // k-invariants: Coriolis factors fomn at (i,j), (i-1,j), (i,j-1); stress terms; running vertical integrals
     {
         double fm0 = 0.0, fmx = 0.0, fmy = 0.0, su_t = 0.0, su_b = 0.0, sv_t = 0.0, sv_b = 0.0;
@@ -1322,6 +1335,11 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
         __syncthreads();
         const V2 tu{su, i0, j0}, tv{sv, i0, j0}, tHu{sHu, i0, j0}, tHv{sHv, i0, j0}, tW{sW, i0, j0};
         const V1 tHz{sHz, i0, j0};
+        double UFx_w = 0.0, UFx_e = 0.0, VFx_w = 0.0, VFx_e = 0.0;
+        if (SH) {
+            UFx_w = f_UFx<C2>(tu, tHu, i - 1, j, 0, g); VFx_w = f_VFx<C2>(tv, tHu, i, j, 0, g);
+            UFx_e = from_east_lane(UFx_w); VFx_e = from_east_lane(VFx_w);
+        }
         if (au) {
             double r = rru;
             if (use_cor) {
@@ -1329,7 +1347,8 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
                 const double UFx_im1 = 0.5 * tHz(i - 1, j, 0) * inv[1 * NT] * (tv(i - 1, j, 0) + tv(i - 1, j + 1, 0));
                 r += 0.5 * (UFx_i + UFx_im1);
             }
-            r -= ((f_UFx<C2>(tu, tHu, i, j, 0, g) - f_UFx<C2>(tu, tHu, i - 1, j, 0, g)) +
+            if (!SH) { UFx_e = f_UFx<C2>(tu, tHu, i, j, 0, g); UFx_w = f_UFx<C2>(tu, tHu, i - 1, j, 0, g); }
+            r -= ((UFx_e - UFx_w) +
                   (f_UFe<C2>(tu, tHv, i, j + 1, 0, g) - f_UFe<C2>(tu, tHv, i, j, 0, g)));
             const double w0 = W1, w1 = tW(i - 1, j, 0);
             const double wpart = C2 ? 0.0 : ((9.0 / 16.0) * (w0 + w1) - (1.0 / 16.0) * (tW(i + 1, j, 0) + tW(i - 2, j, 0)));
@@ -1349,7 +1368,8 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
                 const double VFe_jm1 = 0.5 * tHz(i, j - 1, 0) * inv[2 * NT] * (tu(i, j - 1, 0) + tu(i + 1, j - 1, 0));
                 r -= 0.5 * (VFe_j + VFe_jm1);
             }
-            r -= ((f_VFx<C2>(tv, tHu, i + 1, j, 0, g) - f_VFx<C2>(tv, tHu, i, j, 0, g)) +
+            if (!SH) { VFx_e = f_VFx<C2>(tv, tHu, i + 1, j, 0, g); VFx_w = f_VFx<C2>(tv, tHu, i, j, 0, g); }
+            r -= ((VFx_e - VFx_w) +
                   (f_VFe<C2>(tv, tHv, i, j, 0, g) - f_VFe<C2>(tv, tHv, i, j - 1, 0, g)));
             const double w0 = W1, w1 = tW(i, j - 1, 0);
             const double wpart = C2 ? 0.0 : ((9.0 / 16.0) * (w0 + w1) - (1.0 / 16.0) * (tW(i, j + 1, 0) + tW(i, j - 2, 0)));
@@ -1396,7 +1416,9 @@ extern "C" int rh_rhs_uv_3d(rh_ctx *c, rh_box xbx, rh_box ybx, rh_array4 uold, r
     if (c->unfused) {           // RH_UNFUSED=1: the direct-from-global form, kept as the A/B reference of the tiled kernel
         if (c->prm.uv_c2) k_rhs_uv_3d<1><<<grid2(un), rh_block(), 0, c->stream>>>(RH_UVARGS); else k_rhs_uv_3d<0><<<grid2(un), rh_block(), 0, c->stream>>>(RH_UVARGS);
     } else {
-        if (c->prm.uv_c2) k_rhs_uv_tiled<1><<<rt_grid(un), rt_block(), 0, c->stream>>>(RH_UVARGS); else k_rhs_uv_tiled<0><<<rt_grid(un), rt_block(), 0, c->stream>>>(RH_UVARGS);
+        dim3 gs = rt_grid(un); gs.x = (unsigned)((un.hi[0] - un.lo[0] + RT_BX - 1) / (RT_BX - 1));        // tiles advance by 63 columns (SH = 1)
+        if (c->no_xshare) { if (c->prm.uv_c2) k_rhs_uv_tiled<1, 0><<<rt_grid(un), rt_block(), 0, c->stream>>>(RH_UVARGS); else k_rhs_uv_tiled<0, 0><<<rt_grid(un), rt_block(), 0, c->stream>>>(RH_UVARGS); }
+        else if (c->prm.uv_c2) k_rhs_uv_tiled<1, 1><<<gs, rt_block(), 0, c->stream>>>(RH_UVARGS); else k_rhs_uv_tiled<0, 1><<<gs, rt_block(), 0, c->stream>>>(RH_UVARGS);
     }
 #undef RH_UVARGS
     RH_LAUNCH_CHECK(); return 0;

@@ -8,6 +8,8 @@
   a number (the default drops the coefficient loads and one division per level: FC(k) is CF(k-1) before its scaling, bit for bit).
 * RH_NO_FLATSTRETCH=1: stretch_transform as the tiled kernel even when its arrays are dense over its box (the default then walks the
   plane linearly, 256 columns per block).
+* RH_NO_XSHARE=1: k_rhs_uv_tiled evaluates all eight horizontal fluxes of a point itself (the default takes the two east ones from the
+  neighbouring lane by a DPP shift and advances its tiles by 63 columns).
 * RH_NO_RHOFUSE=1: rho_eos (+ the hydrostatic pressure) and prsgrd as two launches with rho and P in memory (the default marches them as
   one kernel, k_rho_prsgrd, and keeps both in LDS).
 * RH_POISON=1 fills the library's work arrays with NaN at the top of every step: a kernel that read scratch it had not written
@@ -48,7 +50,7 @@ def _phases(cfg, nsteps, what):
     rem.close(); orc.close()
 
 
-@pytest.mark.parametrize("switch", ["RH_NOFUSE2D", "RH_NOREGSOLVE", "RH_POISON", "RH_NO_ASYNC", "RH_NO_BC2D", "RH_NO_MFFUSE", "RH_VMIX_REWRITE", "RH_NO_RHOFUSE", "RH_NO_CKONST", "RH_NO_FLATSTRETCH"])
+@pytest.mark.parametrize("switch", ["RH_NOFUSE2D", "RH_NOREGSOLVE", "RH_POISON", "RH_NO_ASYNC", "RH_NO_BC2D", "RH_NO_MFFUSE", "RH_VMIX_REWRITE", "RH_NO_RHOFUSE", "RH_NO_CKONST", "RH_NO_FLATSTRETCH", "RH_NO_XSHARE"])
 @pytest.mark.parametrize("case", ["Seamount", "DoubleGyre"])
 def test_switch_keeps_the_bits(switch, case, monkeypatch):
     monkeypatch.setenv(switch, "1")
