@@ -793,7 +793,7 @@ k_prsgrd_uv_tiled(B3 ub, B3 vb, B3 un, A4 ru, A4 rv, A4 pn, A4 pm, A4 rho, A4 P,
 // leaves.  Halo columns are marched once per sharing block: the same operands through the same expressions, hence the same bits.
 // bvf, rhoA, rhoS (wanted on the cell box grown by two, REMORA_setup_step.cpp:166-200) are stored by the block that owns the
 // point: the block whose tile holds the point clamped into the box of momentum points.
-#define RP_BY 11       // rows of momentum points per block
+#define RP_BY 12       // rows of momentum points per block
 #define RP_WAVES 16    // wavefronts per block: RP_BY own the tile, the rest march the halo ring
 // what a marching column carries from level to level.  k_rho_eos_P's r_up / z_up are r_k / z_k here and its raw slopes dRraw_k / dZraw_k
 // are r_k1 - r_k / z_k1 - z_k, formed again where they are used: the same operands through the same operation, hence the same bits,
@@ -853,14 +853,20 @@ __device__ __forceinline__ double rp_P0(const RPState &q, const RPConst &c)     
     const double rz_avg = (q.r_k1 + q.r_k) * (q.z_k1 - q.z_k);
     return q.Pk1 + HalfGRho * (rz_avg - OneFifth * ((q.dRh_k1 - dRh_k) * z_diff - (q.dZh_k1 - dZh_k) * rho_diff));
 }
-// Block = 16 wavefronts: RP_BY = 11 of them own the tile's 64 x 11 momentum points (and march those columns), the other five march
-// the 316 columns of the halo ring -- ONE column per thread (two per thread did not fit 128 registers: 49 spilled), 1020 of 1024
-// threads busy in the march, the eleven tile waves alone in the momentum stage.
+// Block = 16 wavefronts: RP_BY = 12 of them own the tile's 64 x 12 momentum points (and march those columns), the other four march
+// the 237 columns of the halo ring -- ONE column per thread (two per thread did not fit 128 registers: 49 spilled), 1005 of 1024
+// threads busy in the march, the twelve tile waves alone in the momentum stage.  The ring is as wide as the stencil of a momentum
+// point: two cells below (i-2, j-2), ONE above (i+1, j+1) -- with two on every side (68 x 15 columns for 64 x 11 points) every output
+// point cost 1.45 evaluations of the equation of state, now 1.31.
+struct RPTile {
+    static constexpr int PX = RT_BX + 3, PY = RP_BY + 3, SIZE = PX * PY, NROWCELLS = 3 * PX, NHALO = NROWCELLS + 3 * RP_BY;
+};
+struct RPView { const double *s; int i0, j0; __device__ __forceinline__ double operator()(int i, int j, int) const { return s[(j - j0 + 2) * RPTile::PX + (i - i0 + 2)]; } };
 __global__ void __launch_bounds__(RT_BX * RP_WAVES)
 k_rho_prsgrd(B3 gb, B3 ub, B3 vb, B3 un, A4 st, A4 rhoA, A4 rhoS, A4 bvf, A4 Hz, A4 z_w, A4 z_r, A4 h, A4 mskr,
              A4 ru, A4 rv, A4 pn, A4 pm, A4 msku, A4 mskv, int nrhs, int N, RPConst cst)
 {
-    typedef Tile<2, 2, RP_BY> T2;
+    typedef RPTile T2;
     constexpr int SZ = T2::SIZE + 4;                        // + a spare slot: the four threads without a column park their values there
     static_assert(T2::NHALO <= RT_BX * (RP_WAVES - RP_BY), "one halo column per thread of the halo waves");
     __shared__ double lds[13 * SZ];                         // rho, z_r, Hz: three levels each; P: two; msku, mskv
@@ -879,8 +885,8 @@ k_rho_prsgrd(B3 gb, B3 ub, B3 vb, B3 un, A4 st, A4 rhoA, A4 rhoS, A4 bvf, A4 Hz,
         has = t < T2::NHALO;
         x = 0; y = 0;
         if (has) {
-            if (t < T2::NROWCELLS) { const int r = t / T2::PX; x = t - r * T2::PX; y = r < 2 ? r : RP_BY + r; }
-            else { const int u = t - T2::NROWCELLS; const int r = u / 4; const int xx = u - r * 4; y = 2 + r; x = xx < 2 ? xx : RT_BX + xx; }
+            if (t < T2::NROWCELLS) { const int r = t / T2::PX; x = t - r * T2::PX; y = r < 2 ? r : RP_BY + 2; }
+            else { const int u = t - T2::NROWCELLS; const int r = u / 3; const int xx = u - r * 3; y = 2 + r; x = xx < 2 ? xx : RT_BX + 2; }
         }
     }
     const int gi = i0 - 2 + x, gj = j0 - 2 + y;             // the column's cell
@@ -919,7 +925,7 @@ k_rho_prsgrd(B3 gb, B3 ub, B3 vb, B3 un, A4 st, A4 rhoA, A4 rhoS, A4 bvf, A4 Hz,
     };
     auto momentum = [&](int kk) {                            // ru, rv of level kk from the staged tiles (k_prsgrd_uv_tiled)
         const int r3 = kk % 3;
-        const TView<2, 2, RP_BY> vr{sR + r3 * SZ, i0, j0}, vz{sZ + r3 * SZ, i0, j0}, vh{sH + r3 * SZ, i0, j0}, vp{sP + (kk & 1) * SZ, i0, j0};
+        const RPView vr{sR + r3 * SZ, i0, j0}, vz{sZ + r3 * SZ, i0, j0}, vh{sH + r3 * SZ, i0, j0}, vp{sP + (kk & 1) * SZ, i0, j0};
         if (au) ru(gi, gj, kk, nrhs) = prsgrd_point(vr, vz, vp, vh, gi, gj, kk, 1, 0, sMu[l0 - 1], sMu[l0], sMu[l0 + 1], on_u, HalfGRho);
         if (av) rv(gi, gj, kk, nrhs) = prsgrd_point(vr, vz, vp, vh, gi, gj, kk, 0, 1, sMv[l0 - T2::PX], sMv[l0], sMv[l0 + T2::PX], om_v, HalfGRho);
     };
