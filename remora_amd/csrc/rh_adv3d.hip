@@ -1035,41 +1035,49 @@ k_tracers_tiled(B3 bx, A4 adv /* cons_old | sstore */, A4 cnew, A4 sst, A4 Hz, A
     // this thread's halo cell in each tile shape (the three tracer tiles share the geometry of `adv`)
     const HaloCell ht = halo_cell<2, 2>(adv, i0, j0, tx, ty), hu = halo_cell<1, 0>(Huon, i0, j0, tx, ty),
                    hv = halo_cell<0, 1>(Hvom, i0, j0, tx, ty), hh = halo_cell<1, 1>(Hz, i0, j0, tx, ty);
-    // per-tracer views, vertical register window t(k-1), t(k), t(k+1), t(k+2), and the values staged for the current level
-    A4 av[RH_NCONS];
-    double wm1[RH_NCONS], w0[RH_NCONS], wp1[RH_NCONS], wp2[RH_NCONS], FCk[RH_NCONS], cn[RH_NCONS], tha[RH_NCONS];
+    // Column cursors (rh_tile.h) that can always be dereferenced: a point outside its array, a thread outside the box or without a halo
+    // cell reads an element that exists and whose value nobody uses, so every load of a level is issued unconditionally -- round 2 had
+    // an exec-mask branch around each of the 16, and at a join of paths with different numbers of loads in flight hipcc waits for all of
+    // them (vmcnt(0)), which pins the prefetch distance to one level.
+    const double *ca[RH_NCONS], *cc[RH_NCONS], *qa[RH_NCONS];
 #pragma unroll
     for (int n = 0; n < RH_NCONS; n++) {
-        av[n] = adv; av[n].p = adv.p + (long)adv.sn * n;
-        wm1[n] = 0.0; w0[n] = ld_in(av[n], i, j, 0); wp1[n] = ld_in(av[n], i, j, 1); wp2[n] = (2 <= N) ? ld_in(av[n], i, j, 2) : 0.0;
-        FCk[n] = 0.0;
-        cn[n] = act ? cnew(i, j, 0, n) : 0.0;
-        tha[n] = halo_ld(av[n], ht, 0);
+        A4 an = adv; an.p = adv.p + (long)adv.sn * n;
+        ca[n] = col_base_any(an, i, j); cc[n] = col_base_any(cnew, ic, jc, n); qa[n] = halo_base_any(an, ht);
     }
-    double Hu0 = ld_in(Huon, i, j, 0), Hv0 = ld_in(Hvom, i, j, 0), hz = ld_in(Hz, i, j, 0);
-    double uha = halo_ld(Huon, hu, 0), vha = halo_ld(Hvom, hv, 0), hha = (MODE == 0) ? halo_ld(Hz, hh, 0) : 0.0;
-    double Wk = ld_in(W, i, j, 0), Wk1 = ld_in(W, i, j, 1);
-    for (int k = 0; k <= N; k++) {
+    const double *cHu = col_base_any(Huon, i, j), *cHv = col_base_any(Hvom, i, j), *cHz = col_base_any(Hz, i, j), *cW = col_base_any(W, i, j);
+    const double *qHu = halo_base_any(Huon, hu), *qHv = halo_base_any(Hvom, hv), *qHz = halo_base_any(Hz, hh);
+    // The operands of level k, requested TWO levels ahead: cnew(k), the halo cell of the advected field, its own point at k + 2 (the new
+    // top of the 4-level vertical window), Huon / Hvom / Hz own and halo, W(k + 1).  Two register sets, the loop unrolled by two: a set is
+    // consumed at the top of its level (tiles, window, the values the level's arithmetic keeps) and refilled at once for level k + 2;
+    // no copy ties a set to the wait of the other, so a wave waits for the older level only.
+    struct Lv { double cn[RH_NCONS], th[RH_NCONS], nx[RH_NCONS], Hu, Hv, hz, uh, vh, hh, W1; };
+    auto load = [&](int k) -> Lv {
+        const int kc = k < N ? k : N, k2 = k + 2 < N ? k + 2 : N, kw = k + 1 < N + 1 ? k + 1 : N + 1;
+        Lv v;
+#pragma unroll
+        for (int n = 0; n < RH_NCONS; n++) { v.cn[n] = cc[n][(unsigned)kc * cnew.sz]; v.th[n] = qa[n][(unsigned)kc * adv.sz]; v.nx[n] = ca[n][(unsigned)k2 * adv.sz]; }
+        v.Hu = cHu[(unsigned)kc * Huon.sz]; v.Hv = cHv[(unsigned)kc * Hvom.sz]; v.hz = cHz[(unsigned)kc * Hz.sz];
+        v.uh = qHu[(unsigned)kc * Huon.sz]; v.vh = qHv[(unsigned)kc * Hvom.sz]; v.hh = (MODE == 0) ? qHz[(unsigned)kc * Hz.sz] : 0.0;
+        v.W1 = cW[(unsigned)kw * W.sz];
+        return v;
+    };
+    double wm1[RH_NCONS], w0[RH_NCONS], wp1[RH_NCONS], wp2[RH_NCONS], FCk[RH_NCONS], cn[RH_NCONS];
+#pragma unroll
+    for (int n = 0; n < RH_NCONS; n++) { wm1[n] = 0.0; w0[n] = ca[n][0]; wp1[n] = ca[n][(unsigned)(1 < N ? 1 : N) * adv.sz]; wp2[n] = 0.0; FCk[n] = 0.0; cn[n] = 0.0; }
+    double Wk = cW[0];
+    auto level = [&](int k, Lv &S, int knext) {
         double *set = lds + (k & 1) * SET;
         double *st[RH_NCONS];
 #pragma unroll
-        for (int n = 0; n < RH_NCONS; n++) { st[n] = set + n * TT::SIZE; tile_put<2, 2>(st[n], tx, ty, w0[n], ht, tha[n]); }
+        for (int n = 0; n < RH_NCONS; n++) { st[n] = set + n * TT::SIZE; tile_put<2, 2>(st[n], tx, ty, w0[n], ht, S.th[n]); }
         double *su = set + RH_NCONS * TT::SIZE, *sv = su + TU::SIZE, *sh = sv + TV::SIZE;
-        tile_put<1, 0>(su, tx, ty, Hu0, hu, uha); tile_put<0, 1>(sv, tx, ty, Hv0, hv, vha);
-        if (MODE == 0) tile_put<1, 1>(sh, tx, ty, hz, hh, hha);
-        // ---- prefetch level k+1 (own points, halo cells, the window's new top level) while level k is computed
-        const bool more = k + 1 <= N;
-        double cn_n[RH_NCONS], tha_n[RH_NCONS], nx2[RH_NCONS];
+        tile_put<1, 0>(su, tx, ty, S.Hu, hu, S.uh); tile_put<0, 1>(sv, tx, ty, S.Hv, hv, S.vh);
+        if (MODE == 0) tile_put<1, 1>(sh, tx, ty, S.hz, hh, S.hh);
+        const double Hu0 = S.Hu, Hv0 = S.Hv, hz = S.hz, Wk1 = S.W1;
 #pragma unroll
-        for (int n = 0; n < RH_NCONS; n++) {
-            cn_n[n] = (more && act) ? cnew(i, j, k + 1, n) : 0.0;
-            tha_n[n] = more ? halo_ld(av[n], ht, k + 1) : 0.0;
-            nx2[n] = (k + 3 <= N) ? ld_in(av[n], i, j, k + 3) : 0.0;
-        }
-        const double Hu0_n = more ? ld_in(Huon, i, j, k + 1) : 0.0, Hv0_n = more ? ld_in(Hvom, i, j, k + 1) : 0.0, hz_n = more ? ld_in(Hz, i, j, k + 1) : 0.0;
-        const double uha_n = more ? halo_ld(Huon, hu, k + 1) : 0.0, vha_n = more ? halo_ld(Hvom, hv, k + 1) : 0.0;
-        const double hha_n = (MODE == 0 && more) ? halo_ld(Hz, hh, k + 1) : 0.0;
-        const double Wk2 = more ? ld_in(W, i, j, k + 2) : 0.0;
+        for (int n = 0; n < RH_NCONS; n++) { cn[n] = S.cn[n]; wp2[n] = S.nx[n]; }
+        S = load(knext);                                   // level k + 2 into the set that has just been consumed
         __syncthreads();
         if (act) {
             const double Hu1 = su[(ty)*TU::PX + tx + 2], Hv1 = sv[(ty + 2) * TV::PX + tx];
@@ -1123,8 +1131,13 @@ k_tracers_tiled(B3 bx, A4 adv /* cons_old | sstore */, A4 cnew, A4 sst, A4 Hz, A
             }
         }
 #pragma unroll
-        for (int n = 0; n < RH_NCONS; n++) { wm1[n] = w0[n]; w0[n] = wp1[n]; wp1[n] = wp2[n]; wp2[n] = nx2[n]; cn[n] = cn_n[n]; tha[n] = tha_n[n]; }
-        Hu0 = Hu0_n; Hv0 = Hv0_n; hz = hz_n; uha = uha_n; vha = vha_n; hha = hha_n; Wk = Wk1; Wk1 = Wk2;
+        for (int n = 0; n < RH_NCONS; n++) { wm1[n] = w0[n]; w0[n] = wp1[n]; wp1[n] = wp2[n]; }
+        Wk = Wk1;
+    };
+    Lv A = load(0), B = load(1);
+    for (int k = 0; k <= N; k += 2) {
+        level(k, A, k + 2);
+        if (k + 1 <= N) level(k + 1, B, k + 3);
     }
 }
 

@@ -105,6 +105,14 @@ __device__ __forceinline__ ColPtr halo_ptr_any(const A4 &a, const HaloCell &h)
     return c;
 }
 __device__ __forceinline__ double col_ldu(const ColPtr &c, int k) { return c.p[(unsigned)k * c.sz]; }
+// The same with the level stride left to the array (one scalar for all cursors of an array instead of a vector register per cursor): the
+// stand-in for a point outside the array is the array's first column, every level of which exists.
+__device__ __forceinline__ double *col_base_any(const A4 &a, int i, int j, int n = 0)
+{
+    const bool in = i >= a.lo0 && i <= a.hi0 && j >= a.lo1 && j <= a.hi1;
+    return a.p + ((long)a.ix(in ? i : a.lo0, in ? j : a.lo1, a.lo2) + (long)n * a.sn - (long)a.lo2 * a.sz);
+}
+__device__ __forceinline__ double *halo_base_any(const A4 &a, const HaloCell &h) { return a.p + ((h.lds >= 0 ? (long)h.g : 0L) - (long)a.lo2 * a.sz); }
 __device__ __forceinline__ void col_st(const ColPtr &c, int k, double v) { c.p[(unsigned)k * c.sz] = v; }
 
 // The same for kernels whose threads only ever touch their own column: a view with the call syntax of A4 whose (i, j) arguments are
