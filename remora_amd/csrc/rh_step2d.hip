@@ -609,6 +609,9 @@ k2d_fused(K2Args a0)
             corV = 0.5 * d * fm * (ubr(i, j, 0) + ubr(i + 1, j, 0));
         }
     }
+    // mskp * 0.125 (mix_p_metrics) must not be formed where mskp is loaded: hipcc hoists the product to the load, and its wait for that
+    // one value (vmcnt(0) in the middle of the load phase) held back every load after it when the masks are read
+    asm volatile("" : "+v"(mp0));
     if (in_un) {
         UFe = s2_UFe(ubr, DVom, i, j, P);
         VFx = s2_VFx(vbr, DUon, i, j, P);
