@@ -106,7 +106,6 @@ __device__ __forceinline__ RhTile rh_tile_patch()
 
 // Dynamic LDS of the one-wavefront column kernels.  Up to 64 KB needs no opt-in; above that (deep columns: nz >= 63 for the
 // tridiagonal solver) the kernel is raised to what it asks for, up to half the CU's 160 KB so that two wavefronts still share a CU.
-#define RH_DUMP_DOUBLES 8192
 #define RH_LDS_MAX (80 * 1024)
 template <class K> static inline hipError_t rh_lds_optin(K kernel, size_t bytes)
 {
@@ -146,7 +145,6 @@ struct rh_ctx {
     rh_array4 rho, P, W, wCF, wDC, DUon, DVom, Drhs, Dnew, zwrk, gzeta, gzeta2, gzetaSA;
     rh_array4 gW1, gW2, gW3, gS2C, gB2, gS2;      // GLS corrector scratch (allocated only with vmix_mode = RH_VMIX_GLS)
     double *d_work = nullptr; long work_bytes = 0;
-    double *d_dump = nullptr;        // RH_DUMP_DOUBLES of scratch nobody reads: where threads without an output point send their (unconditional) stores
     // RCCL
     void *comm = nullptr; int rank = 0, nranks = 1;
     rh_exchange_fn xfn = nullptr; void *xuser = nullptr;      // transport of the ghost exchange (RCCL by default)

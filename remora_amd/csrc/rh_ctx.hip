@@ -483,12 +483,10 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
             return bad("gls parameters: gls_n must be non-zero; cmu0, sigk, sigp, Kmin, Pmin positive");
     }
     long n = 0; for (rh_array4 *a : ws) n += align32(a4_size(*a));
-    n += RH_DUMP_DOUBLES;
     c->work_bytes = n * 8;
     e = hipMalloc((void **)&c->d_work, c->work_bytes);
     if (e != hipSuccess) { c->d_work = nullptr; char m[96]; snprintf(m, sizeof m, "hipMalloc(%ld bytes of work space)", n * 8); return bad_hip(m, e); }
     double *p = c->d_work; for (rh_array4 *a : ws) { a->p = p; p += align32(a4_size(*a)); }
-    c->d_dump = p;
     e = hipMemsetAsync(c->d_work, 0, c->work_bytes, c->stream);
     if (e != hipSuccess) return bad_hip("hipMemsetAsync", e);
     if (diag_scratch_init(c)) { const std::string m = g_rh_err; return bad(m.c_str()); }
