@@ -785,8 +785,8 @@ k_prsgrd_uv_tiled(B3 ub, B3 vb, B3 un, A4 ru, A4 rv, A4 pn, A4 pm, A4 rho, A4 P,
 // ---- rho_eos + the hydrostatic pressure + the horizontal differences of prsgrd in ONE downward march (setup_step.cpp:200 and :262-266:
 // nothing between the two calls touches their operands).  k_rho_eos_P + k_prsgrd_uv_tiled hand rho and P over through HBM (written
 // once, read 1.2-1.3 times with the halo rows) although both are column-local functions of T, S, Hz, z_r.  Here a block owns a
-// 64 x 11 tile of momentum points and marches EVERY column of the tile grown by two cells (68 x 15 = 1020 columns, one per thread of
-// the block's 16 wavefronts).  Per level a column forms rho(k) from T, S (rho_eos.cpp:54-59),
+// 64 x 12 tile of momentum points and marches EVERY column of the tile grown by the stencil of a momentum point -- two cells below,
+// one above (67 x 15 = 1005 columns, one per thread of the block's 16 wavefronts; see RPTile).  Per level a column forms rho(k) from T, S (rho_eos.cpp:54-59),
 // the column sums and bvf (:69-98) and prsgrd's P(k+1) one level behind (prsgrd.cpp:54-99) -- the body of k_rho_eos_P -- and puts
 // rho, z_r, Hz of level k (ring of three levels) and P(k+1) (two) into LDS; after the barrier the tile's threads form ru, rv of
 // level k+1 from LDS with k_prsgrd_uv_tiled's own expression.  rho and P never reach memory: 14 -> ~8 doubles per cell for the two
