@@ -184,7 +184,7 @@ struct rh_ctx {
     // remember which arrays hold the constants), and the column solvers the drivers launch read the constants from four short rows
     // (d_vmixrow: Akv, Akt x 3; zero row / level strides, so every load hits L1) instead of streaming the 3-D arrays.  Same values,
     // same expressions: bit-identical.  RH_VMIX_REWRITE=1 goes back to the per-step rewrite and the array reads (A/B parity and timing).
-    double *d_vmixrow = nullptr; int vmixrow_len = 0; const double *vmix_akv_done = nullptr, *vmix_akt_done = nullptr; bool vmix_rewrite = false; bool no_ckonst = false, no_flatstretch = false, no_xshare = false;   // RH_NO_CKONST=1: the register solvers read the constant rows instead of taking the constant as a number (A/B parity)
+    double *d_vmixrow = nullptr; int vmixrow_len = 0; const double *vmix_akv_done = nullptr, *vmix_akt_done = nullptr; bool vmix_rewrite = false; bool no_ckonst = false, no_flatstretch = false, no_xshare = false, no_k2mode = false;   // RH_NO_CKONST=1: the register solvers read the constant rows instead of taking the constant as a number (A/B parity)
    
     ~rh_ctx() { if (bcq) bc_queue_delete(bcq); if (haloq) halo_queue_delete(haloq); }
 };

@@ -434,6 +434,7 @@ extern "C" int rh_create(const rh_params *prm, void *stream, rh_ctx **out)
     c->no_rhofuse = getenv("RH_NO_RHOFUSE") && atoi(getenv("RH_NO_RHOFUSE")) != 0;
     c->vmix_rewrite = getenv("RH_VMIX_REWRITE") && atoi(getenv("RH_VMIX_REWRITE")) != 0;
     c->no_ckonst = getenv("RH_NO_CKONST") && atoi(getenv("RH_NO_CKONST")) != 0;
+    c->no_k2mode = getenv("RH_NO_K2MODE") && atoi(getenv("RH_NO_K2MODE")) != 0;   // k2d_fused always reads its time-stepping modes from the arguments (A/B parity and timing)
     c->no_xshare = getenv("RH_NO_XSHARE") && atoi(getenv("RH_NO_XSHARE")) != 0;   // k_rhs_uv_tiled evaluates all eight horizontal fluxes per thread (A/B parity and timing)
     c->no_flatstretch = getenv("RH_NO_FLATSTRETCH") && atoi(getenv("RH_NO_FLATSTRETCH")) != 0;   // stretch_transform always as the tiled kernel (A/B parity and timing)
 

@@ -410,6 +410,17 @@ __device__ __forceinline__ void k2_frame_point(const K2Args &L, int g)
 // and may run while the exchanges of this call and the ghost fill of the previous one are still in flight.
 __host__ __device__ __forceinline__ bool k2_tile_is_interior(const B2v &vb, int I0, int J0)
 { return I0 - 2 >= vb.lo0 + 3 && I0 - 2 + F_PX - 1 <= vb.hi0 - 3 && J0 - 2 >= vb.lo1 + 3 && J0 - 2 + F_PY - 1 <= vb.hi1 - 3; }
+// MODE: the two calls that make up all but the first fast step of a baroclinic step are compiled with their time-stepping modes as
+// constants -- 1: predictor, not the first step (leap-frog free surface, both sets of time averages, no coupling terms, two-level
+// momentum); 2: corrector (Adams-Moulton free surface, second set of averages, three-level momentum) -- so their operand sets and
+// arithmetic are straight-line code; 0 reads the modes from the arguments (first fast step, first baroclinic steps).
+#define K2_AVG    (MODE == 1 ? 1 : MODE == 2 ? 2 : zp.avg_mode)
+#define K2_ZMODE  (MODE == 1 ? 1 : MODE == 2 ? 2 : zp.zmode)
+#define K2_ZPRED  (MODE == 1 ? 1 : MODE == 2 ? 0 : zp.predictor)
+#define K2_COUPLE (MODE != 0 ? 0 : P.couple)
+#define K2_AM3    (MODE == 1 ? 0 : MODE == 2 ? 1 : P.am3)
+#define K2_PPRED  (MODE == 1 ? 1 : MODE == 2 ? 0 : P.predictor)
+template <int MODE>
 __global__ void __launch_bounds__(RT_BX * U_BY)
 k2d_fused(K2Args a0)
 {
@@ -474,10 +485,10 @@ k2d_fused(K2Args a0)
         h0 = h(i, j, 0); zr0 = zeta_rhs(i, j, 0); zs0 = zeta_stp(i, j, 0); rS0 = rhoS(i, j, 0); rA0 = rhoA(i, j, 0); vr0 = visc2_r(i, j, 0);
         if (P.use_cor) fc0 = fcor(i, j, 0);
         if (!zp.nomask) mr0 = mskr(i, j, 0);
-        if (zp.zmode == 2) { rzs = rzeta_stp(i, j, 0); rzp = rzeta_pts(i, j, 0); }
+        if (K2_ZMODE == 2) { rzs = rzeta_stp(i, j, 0); rzp = rzeta_pts(i, j, 0); }
         if (owner) {
-            if (zp.avg_mode == 1) { zt0 = Zt_avg1(i, j, 0); dua1 = DU_avg1(i, j, 0); dva1 = DV_avg1(i, j, 0); }
-            if (zp.avg_mode >= 1) { dua2 = DU_avg2(i, j, 0); dva2 = DV_avg2(i, j, 0); }
+            if (K2_AVG == 1) { zt0 = Zt_avg1(i, j, 0); dua1 = DU_avg1(i, j, 0); dva1 = DV_avg1(i, j, 0); }
+            if (K2_AVG >= 1) { dua2 = DU_avg2(i, j, 0); dva2 = DV_avg2(i, j, 0); }
         }
     }
     double vp0 = 0, mp0 = 1.0;
@@ -485,17 +496,17 @@ k2d_fused(K2Args a0)
     double u_frc = 0, u_r0 = 0, u_r1 = 0, u_stp = 0, u_rs = 0, u_rp = 0, u_msk = 1.0, u_zsw = 0;
     if (is_u) {
         u_frc = rufrc(i, j, 0); u_stp = ub_stp(i, j, 0); u_zsw = zeta_stp(i - 1, j, 0);
-        if (P.couple >= 2) u_r0 = ru2d0(i, j, 0);
-        if (P.couple == 3) u_r1 = ru2d1(i, j, 0);
-        if (P.am3) { u_rs = rubar_stp(i, j, 0); u_rp = rubar_pts(i, j, 0); }
+        if (K2_COUPLE >= 2) u_r0 = ru2d0(i, j, 0);
+        if (K2_COUPLE == 3) u_r1 = ru2d1(i, j, 0);
+        if (K2_AM3) { u_rs = rubar_stp(i, j, 0); u_rp = rubar_pts(i, j, 0); }
         if (!P.nomask) u_msk = msku(i, j, 0);
     }
     double v_frc = 0, v_r0 = 0, v_r1 = 0, v_stp = 0, v_rs = 0, v_rp = 0, v_msk = 1.0, v_zss = 0;
     if (is_v) {
         v_frc = rvfrc(i, j, 0); v_stp = vb_stp(i, j, 0); v_zss = zeta_stp(i, j - 1, 0);
-        if (P.couple >= 2) v_r0 = rv2d0(i, j, 0);
-        if (P.couple == 3) v_r1 = rv2d1(i, j, 0);
-        if (P.am3) { v_rs = rvbar_stp(i, j, 0); v_rp = rvbar_pts(i, j, 0); }
+        if (K2_COUPLE >= 2) v_r0 = rv2d0(i, j, 0);
+        if (K2_COUPLE == 3) v_r1 = rv2d1(i, j, 0);
+        if (K2_AM3) { v_rs = rvbar_stp(i, j, 0); v_rp = rvbar_pts(i, j, 0); }
         if (!P.nomask) v_msk = mskv(i, j, 0);
     }
 
@@ -546,11 +557,11 @@ k2d_fused(K2Args a0)
         pm0 = tpmv(i, j, 0); pn0 = tpnv(i, j, 0);
         const double du0 = DUon(i, j, 0), dv0 = DVom(i, j, 0);
         if (owner) {
-            if (zp.avg_mode == 0) {
+            if (K2_AVG == 0) {
                 Zt_avg1(i, j, 0) = 0.0;
                 DU_avg1(i, j, 0) = 0.0; DU_avg2(i, j, 0) = zp.wt_b * du0;
                 DV_avg1(i, j, 0) = 0.0; DV_avg2(i, j, 0) = zp.wt_b * dv0;
-            } else if (zp.avg_mode == 1) {
+            } else if (K2_AVG == 1) {
                 Zt_avg1(i, j, 0) = zt0 + zp.wt_a * zr0;
                 DU_avg1(i, j, 0) = dua1 + zp.wt_a * du0; DU_avg2(i, j, 0) = dua2 + zp.wt_b * du0;
                 DV_avg1(i, j, 0) = dva1 + zp.wt_a * dv0; DV_avg2(i, j, 0) = dva2 + zp.wt_b * dv0;
@@ -561,11 +572,11 @@ k2d_fused(K2Args a0)
         }
         const double div = (du0 - DUon(i + 1, j, 0)) + (dv0 - DVom(i, j + 1, 0));
         const double zs = zs0, mr = mr0;
-        if (zp.zmode == 0) {
+        if (K2_ZMODE == 0) {
             const double cff1 = zp.dtfast;
             zn0 = (zs + pm0 * pn0 * cff1 * div) * mr;
             zw0 = 0.5 * (zs + zn0);
-        } else if (zp.zmode == 1) {
+        } else if (K2_ZMODE == 1) {
             const double cff1 = 2.0 * zp.dtfast, cff4 = 4.0 / 25.0, cff5 = 1.0 - 2.0 * cff4;
             zn0 = (zs + pm0 * pn0 * cff1 * div) * mr;
             zw0 = cff5 * zr0 + cff4 * (zs + zn0);
@@ -588,7 +599,7 @@ k2d_fused(K2Args a0)
                 if (cj) for (int g = 1; g <= 3; g++) zeta_new(i, j + cj * g, 0) = zn0;
                 if (ci && cj) for (int gj = 1; gj <= 3; gj++) for (int gi = 1; gi <= 3; gi++) zeta_new(i + ci * gi, j + cj * gj, 0) = zn0;
             }
-            if (zp.predictor) rzeta_rhs(i, j, 0) = div;                        // :459-464
+            if (K2_ZPRED) rzeta_rhs(i, j, 0) = div;                        // :459-464
         }
     }
     // ---- (5) phase 1 of k2d_uvbar: the shared quantities of this thread's rho and psi point
@@ -655,11 +666,11 @@ k2d_fused(K2Args a0)
             const double cff2 = 0.5 * (pmx + pm0) * (n[Q_MUFE * NT] - mUFe);
             rhs += cff1 + cff2;
         }
-        if (P.couple == 0) rhs += u_frc;
+        if (K2_COUPLE == 0) rhs += u_frc;
         else {
             double f = u_frc;
-            if (P.couple == 1) { f -= rhs; rhs += f; ru2d0(i, j, 0) = f; }
-            else if (P.couple == 2) {
+            if (K2_COUPLE == 1) { f -= rhs; rhs += f; ru2d0(i, j, 0) = f; }
+            else if (K2_COUPLE == 2) {
                 f = f - rhs;
                 const double r0 = u_r0;
                 rhs = rhs + 1.5 * f - 0.5 * r0;
@@ -678,7 +689,7 @@ k2d_fused(K2Args a0)
         const double Dnew_avg = 1.0 / ((zn0 + h0) + (w[Q_ZN * NT] + hx));
         const double mu = u_msk;
         double ubv;
-        if (!P.am3) ubv = (u_stp * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mu;
+        if (!K2_AM3) ubv = (u_stp * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mu;
         else ubv = (u_stp * (Dstp0 + Dstp1) +
                     cff * (P.c1 * rhs + P.c2 * u_rs - P.c3 * u_rp)) * Dnew_avg * mu;
         if (L.wallbc) {
@@ -708,7 +719,7 @@ k2d_fused(K2Args a0)
             }
         }
         ub_new(i, j, 0) = ubv;
-        if (P.predictor) rubar_rhs(i, j, 0) = rhs;
+        if (K2_PPRED) rubar_rhs(i, j, 0) = rhs;
     }
     if (is_v) {
         const double *sp = q - RT_BX, *e = q + 1;
@@ -729,11 +740,11 @@ k2d_fused(K2Args a0)
             const double cff2 = 0.5 * (pmy + pm0) * (mVFe - sp[Q_MVFE * NT]);
             rhs += cff1 - cff2;
         }
-        if (P.couple == 0) rhs += v_frc;
+        if (K2_COUPLE == 0) rhs += v_frc;
         else {
             double f = v_frc;
-            if (P.couple == 1) { f -= rhs; rhs += f; rv2d0(i, j, 0) = f; }
-            else if (P.couple == 2) {
+            if (K2_COUPLE == 1) { f -= rhs; rhs += f; rv2d0(i, j, 0) = f; }
+            else if (K2_COUPLE == 2) {
                 f = f - rhs;
                 const double r0 = v_r0;
                 rhs = rhs + 1.5 * f - 0.5 * r0;
@@ -752,7 +763,7 @@ k2d_fused(K2Args a0)
         const double Dnew_avg = 1.0 / ((zn0 + h0) + (sp[Q_ZN * NT] + hy));
         const double mv = v_msk;
         double vbv;
-        if (!P.am3) vbv = (v_stp * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mv;
+        if (!K2_AM3) vbv = (v_stp * (Dstp0 + Dstp1) + cff * P.c1 * rhs) * Dnew_avg * mv;
         else vbv = (v_stp * (Dstp0 + Dstp1) +
                     cff * (P.c1 * rhs + P.c2 * v_rs - P.c3 * v_rp)) * Dnew_avg * mv;
         if (L.wallbc) {                                      // REMORA_BoundaryConditions_yvel.cpp:55-265, the mirror image
@@ -779,10 +790,16 @@ k2d_fused(K2Args a0)
             }
         }
         vb_new(i, j, 0) = vbv;
-        if (P.predictor) rvbar_rhs(i, j, 0) = rhs;
+        if (K2_PPRED) rvbar_rhs(i, j, 0) = rhs;
     }
     }
 }
+#undef K2_AVG
+#undef K2_ZMODE
+#undef K2_ZPRED
+#undef K2_COUPLE
+#undef K2_AM3
+#undef K2_PPRED
 
 // k2d_flux on the rim only: the points of tbxp3 outside `hole` (the valid box shrunk by 3) -- every ghost face and every face a
 // periodic wrap or a neighbour rank takes its ghost values from.  Same enumeration as k2d_frame.
@@ -1055,14 +1072,24 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
             ka.wallbc = wallbc ? 1 : 0;
             ka.bc_ext[0] = c->extdir[RH_BCV_UBAR][0]; ka.bc_ext[1] = c->extdir[RH_BCV_UBAR][3]; ka.bc_ext[2] = c->extdir[RH_BCV_VBAR][1]; ka.bc_ext[3] = c->extdir[RH_BCV_VBAR][4];
             ka.part = 0;
+            // the kernel's compiled modes (see k2d_fused): steady predictor, steady corrector, or everything from the arguments
+            const int kmode = c->no_k2mode ? 0 :
+                (zp.avg_mode == 1 && zp.zmode == 1 && zp.predictor == 1 && P.couple == 0 && P.am3 == 0 && P.predictor == 1) ? 1 :
+                (zp.avg_mode == 2 && zp.zmode == 2 && zp.predictor == 0 && P.couple == 0 && P.am3 == 1 && P.predictor == 0) ? 2 : 0;
+            auto k2_launch = [&](dim3 g, const K2Args &arg) {
+                const dim3 b(RT_BX, U_BY, 1);
+                if (kmode == 1) k2d_fused<1><<<g, b, 0, c->stream>>>(arg);
+                else if (kmode == 2) k2d_fused<2><<<g, b, 0, c->stream>>>(arg);
+                else k2d_fused<0><<<g, b, 0, c->stream>>>(arg);
+            };
             if (!split) {
-                { TScope tk(c, "k2d_fused"); k2d_fused<<<dim3(grid.x, grid.y + (unsigned)frame_rows, 1), dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ka); }
+                { TScope tk(c, "k2d_fused"); k2_launch(dim3(grid.x, grid.y + (unsigned)frame_rows, 1), ka); }
                 RH_LAUNCH_CHECK();
             } else {
                 if (!c->ev2d_m) { RH_HIP(hipEventCreateWithFlags(&c->ev2d_m, hipEventDisableTiming)); RH_HIP(hipEventCreateWithFlags(&c->ev2d_b, hipEventDisableTiming)); }
                 RH_HIP(hipEventRecord(c->ev2d_m, c->stream));                    // everything up to the previous call's rim tiles
                 K2Args ki = ka; ki.part = 1; ki.nframe = 0;
-                { TScope tk(c, "k2d_fused"); k2d_fused<<<dim3(grid.x, grid.y, 1), dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ki); }
+                { TScope tk(c, "k2d_fused"); k2_launch(dim3(grid.x, grid.y, 1), ki); }
                 RH_LAUNCH_CHECK();
                 RH_TRY(halo_side_enter(c));                                       // c->stream is the side stream from here ...
                 int rc = 0;
@@ -1074,7 +1101,7 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
                 RH_TRY(rc); RH_TRY(rc2);
                 RH_HIP(hipStreamWaitEvent(c->stream, c->ev2d_b, 0));
                 ka.part = 2;
-                { TScope tk(c, "k2d_fused"); k2d_fused<<<dim3(grid.x, grid.y + (unsigned)frame_rows, 1), dim3(RT_BX, U_BY, 1), 0, c->stream>>>(ka); }
+                { TScope tk(c, "k2d_fused"); k2_launch(dim3(grid.x, grid.y + (unsigned)frame_rows, 1), ka); }
                 RH_LAUNCH_CHECK();
                 c->pend2d.on = true; c->pend2d.ubar = s->ubar; c->pend2d.vbar = s->vbar; c->pend2d.zeta = s->zeta;
                 c->pend2d.msku = s->msku; c->pend2d.mskv = s->mskv; c->pend2d.mskr = s->mskr; c->pend2d.knew = knew;

@@ -10,6 +10,8 @@
   plane linearly, 256 columns per block).
 * RH_NO_XSHARE=1: k_rhs_uv_tiled evaluates all eight horizontal fluxes of a point itself (the default takes the two east ones from the
   neighbouring lane by a DPP shift and advances its tiles by 63 columns).
+* RH_NO_K2MODE=1: k2d_fused always reads its time-stepping modes from its arguments (the default runs the steady predictor and corrector
+  calls through instantiations that have them as constants).
 * RH_NO_RHOFUSE=1: rho_eos (+ the hydrostatic pressure) and prsgrd as two launches with rho and P in memory (the default marches them as
   one kernel, k_rho_prsgrd, and keeps both in LDS).
 * RH_POISON=1 fills the library's work arrays with NaN at the top of every step: a kernel that read scratch it had not written
@@ -50,7 +52,7 @@ def _phases(cfg, nsteps, what):
     rem.close(); orc.close()
 
 
-@pytest.mark.parametrize("switch", ["RH_NOFUSE2D", "RH_NOREGSOLVE", "RH_POISON", "RH_NO_ASYNC", "RH_NO_BC2D", "RH_NO_MFFUSE", "RH_VMIX_REWRITE", "RH_NO_RHOFUSE", "RH_NO_CKONST", "RH_NO_FLATSTRETCH", "RH_NO_XSHARE"])
+@pytest.mark.parametrize("switch", ["RH_NOFUSE2D", "RH_NOREGSOLVE", "RH_POISON", "RH_NO_ASYNC", "RH_NO_BC2D", "RH_NO_MFFUSE", "RH_VMIX_REWRITE", "RH_NO_RHOFUSE", "RH_NO_CKONST", "RH_NO_FLATSTRETCH", "RH_NO_XSHARE", "RH_NO_K2MODE"])
 @pytest.mark.parametrize("case", ["Seamount", "DoubleGyre"])
 def test_switch_keeps_the_bits(switch, case, monkeypatch):
     monkeypatch.setenv(switch, "1")
