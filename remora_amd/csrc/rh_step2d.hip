@@ -420,7 +420,11 @@ __host__ __device__ __forceinline__ bool k2_tile_is_interior(const B2v &vb, int 
 #define K2_COUPLE (MODE != 0 ? 0 : P.couple)
 #define K2_AM3    (MODE == 1 ? 0 : MODE == 2 ? 1 : P.am3)
 #define K2_PPRED  (MODE == 1 ? 1 : MODE == 2 ? 0 : P.predictor)
-template <int MODE>
+// FIX = 1: masks known to be one and Coriolis on (every pinned case but the f = 0 ones) as constants as well
+#define K2_ZNOMASK (FIX ? 1 : zp.nomask)
+#define K2_PNOMASK (FIX ? 1 : P.nomask)
+#define K2_COR     (FIX ? 1 : P.use_cor)
+template <int MODE, int FIX>
 __global__ void __launch_bounds__(RT_BX * U_BY)
 k2d_fused(K2Args a0)
 {
@@ -483,8 +487,8 @@ k2d_fused(K2Args a0)
     double h0 = 0, zr0 = 0, zs0 = 0, rS0 = 0, rA0 = 0, fc0 = 0, vr0 = 0, mr0 = 1.0, rzs = 0, rzp = 0, zt0 = 0, dua1 = 0, dua2 = 0, dva1 = 0, dva2 = 0;
     if (in_rb) {
         h0 = h(i, j, 0); zr0 = zeta_rhs(i, j, 0); zs0 = zeta_stp(i, j, 0); rS0 = rhoS(i, j, 0); rA0 = rhoA(i, j, 0); vr0 = visc2_r(i, j, 0);
-        if (P.use_cor) fc0 = fcor(i, j, 0);
-        if (!zp.nomask) mr0 = mskr(i, j, 0);
+        if (K2_COR) fc0 = fcor(i, j, 0);
+        if (!K2_ZNOMASK) mr0 = mskr(i, j, 0);
         if (K2_ZMODE == 2) { rzs = rzeta_stp(i, j, 0); rzp = rzeta_pts(i, j, 0); }
         if (owner) {
             if (K2_AVG == 1) { zt0 = Zt_avg1(i, j, 0); dua1 = DU_avg1(i, j, 0); dva1 = DV_avg1(i, j, 0); }
@@ -492,14 +496,14 @@ k2d_fused(K2Args a0)
         }
     }
     double vp0 = 0, mp0 = 1.0;
-    if (in_un) { vp0 = visc2_p(i, j, 0); if (!P.nomask) mp0 = mskp(i, j, 0); }
+    if (in_un) { vp0 = visc2_p(i, j, 0); if (!K2_PNOMASK) mp0 = mskp(i, j, 0); }
     double u_frc = 0, u_r0 = 0, u_r1 = 0, u_stp = 0, u_rs = 0, u_rp = 0, u_msk = 1.0, u_zsw = 0;
     if (is_u) {
         u_frc = rufrc(i, j, 0); u_stp = ub_stp(i, j, 0); u_zsw = zeta_stp(i - 1, j, 0);
         if (K2_COUPLE >= 2) u_r0 = ru2d0(i, j, 0);
         if (K2_COUPLE == 3) u_r1 = ru2d1(i, j, 0);
         if (K2_AM3) { u_rs = rubar_stp(i, j, 0); u_rp = rubar_pts(i, j, 0); }
-        if (!P.nomask) u_msk = msku(i, j, 0);
+        if (!K2_PNOMASK) u_msk = msku(i, j, 0);
     }
     double v_frc = 0, v_r0 = 0, v_r1 = 0, v_stp = 0, v_rs = 0, v_rp = 0, v_msk = 1.0, v_zss = 0;
     if (is_v) {
@@ -507,7 +511,7 @@ k2d_fused(K2Args a0)
         if (K2_COUPLE >= 2) v_r0 = rv2d0(i, j, 0);
         if (K2_COUPLE == 3) v_r1 = rv2d1(i, j, 0);
         if (K2_AM3) { v_rs = rvbar_stp(i, j, 0); v_rp = rvbar_pts(i, j, 0); }
-        if (!P.nomask) v_msk = mskv(i, j, 0);
+        if (!K2_PNOMASK) v_msk = mskv(i, j, 0);
     }
 
     // ---- (2) staged tiles: Drhs (advance_2d.cpp:149-152), ubar / vbar(krhs), pm, pn
@@ -613,7 +617,7 @@ k2d_fused(K2Args a0)
         const double cffr = mix_r_cff(r, Drhs, ubr, vbr, i, j, 0);
         mUFx = r.on_r * r.on_r * r.visc * cffr;
         mVFe = r.om_r * r.om_r * r.visc * cffr;
-        if (P.use_cor) {
+        if (K2_COR) {
             const double fm = fc0 * (1.0 / (pm0 * pn0));
             const double d = Drhs(i, j, 0);
             corU = 0.5 * d * fm * (vbr(i, j, 0) + vbr(i, j + 1, 0));
@@ -660,7 +664,7 @@ k2d_fused(K2Args a0)
             const double cff2 = n[Q_UFE * NT] - UFe;
             rhs -= (cff1 + cff2);
         }
-        if (P.use_cor) rhs += 0.5 * (corU + w[Q_CORU * NT]);
+        if (K2_COR) rhs += 0.5 * (corU + w[Q_CORU * NT]);
         {
             const double cff1 = 0.5 * (pnx + pn0) * (mUFx - w[Q_MUFX * NT]);
             const double cff2 = 0.5 * (pmx + pm0) * (n[Q_MUFE * NT] - mUFe);
@@ -696,7 +700,7 @@ k2d_fused(K2Args a0)
             // REMORA_BoundaryConditions_xvel.cpp:56-265 for walls on all sides, as its passes leave ubar(knew): ext_dir on the wall
             // face and the two ghost faces behind it; foextrap (x msku) into the two ghost rows; 0.5 * (side + row) in the corners
             const V2 msku{L.A.smu, L.A.msku};
-            auto MU = [&](int ii, int jj) -> double { return P.nomask ? 1.0 : msku(ii, jj, 0); };
+            auto MU = [&](int ii, int jj) -> double { return K2_PNOMASK ? 1.0 : msku(ii, jj, 0); };
             const bool xlo = (i == P.dlox), xhi = (i == P.dhix + 1);
             if (xlo || xhi) {
                 const double ext = xlo ? L.bc_ext[0] : L.bc_ext[1]; const int sgn = xlo ? -1 : 1;
@@ -734,7 +738,7 @@ k2d_fused(K2Args a0)
             const double cff2 = VFe - sp[Q_VFE * NT];
             rhs -= (cff1 + cff2);
         }
-        if (P.use_cor) rhs -= 0.5 * (corV + sp[Q_CORV * NT]);
+        if (K2_COR) rhs -= 0.5 * (corV + sp[Q_CORV * NT]);
         {
             const double cff1 = 0.5 * (pny + pn0) * (e[Q_MVFX * NT] - mVFx);
             const double cff2 = 0.5 * (pmy + pm0) * (mVFe - sp[Q_MVFE * NT]);
@@ -768,7 +772,7 @@ k2d_fused(K2Args a0)
                     cff * (P.c1 * rhs + P.c2 * v_rs - P.c3 * v_rp)) * Dnew_avg * mv;
         if (L.wallbc) {                                      // REMORA_BoundaryConditions_yvel.cpp:55-265, the mirror image
             const V2 mskv{L.A.smv, L.A.mskv};
-            auto MV = [&](int ii, int jj) -> double { return P.nomask ? 1.0 : mskv(ii, jj, 0); };
+            auto MV = [&](int ii, int jj) -> double { return K2_PNOMASK ? 1.0 : mskv(ii, jj, 0); };
             const bool ylo = (j == P.dloy), yhi = (j == P.dhiy + 1);
             if (ylo || yhi) {
                 const double ext = ylo ? L.bc_ext[2] : L.bc_ext[3]; const int sgn = ylo ? -1 : 1;
@@ -794,6 +798,9 @@ k2d_fused(K2Args a0)
     }
     }
 }
+#undef K2_ZNOMASK
+#undef K2_PNOMASK
+#undef K2_COR
 #undef K2_AVG
 #undef K2_ZMODE
 #undef K2_ZPRED
@@ -1078,9 +1085,10 @@ extern "C" int rh_advance_2d(rh_ctx *c, rh_state *s, int istep, double dtfast, i
                 (zp.avg_mode == 2 && zp.zmode == 2 && zp.predictor == 0 && P.couple == 0 && P.am3 == 1 && P.predictor == 0) ? 2 : 0;
             auto k2_launch = [&](dim3 g, const K2Args &arg) {
                 const dim3 b(RT_BX, U_BY, 1);
-                if (kmode == 1) k2d_fused<1><<<g, b, 0, c->stream>>>(arg);
-                else if (kmode == 2) k2d_fused<2><<<g, b, 0, c->stream>>>(arg);
-                else k2d_fused<0><<<g, b, 0, c->stream>>>(arg);
+                const bool fix = zp.nomask && P.nomask && P.use_cor;
+                if (kmode == 1) { if (fix) k2d_fused<1, 1><<<g, b, 0, c->stream>>>(arg); else k2d_fused<1, 0><<<g, b, 0, c->stream>>>(arg); }
+                else if (kmode == 2) { if (fix) k2d_fused<2, 1><<<g, b, 0, c->stream>>>(arg); else k2d_fused<2, 0><<<g, b, 0, c->stream>>>(arg); }
+                else k2d_fused<0, 0><<<g, b, 0, c->stream>>>(arg);
             };
             if (!split) {
                 { TScope tk(c, "k2d_fused"); k2_launch(dim3(grid.x, grid.y + (unsigned)frame_rows, 1), ka); }
