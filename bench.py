@@ -77,7 +77,7 @@ GROUP_KERNELS = {
     "prestep_t3": ["k_tracers_tiled<0"], "rhs_t3": ["k_tracers_tiled<1"], "rhs_uv_3d": ["k_rhs_uv_tiled"], "uv3dmix": ["k_uv3dmix_tiled"],
     "uv_corrector": ["k_column_solver_reg<1, 0, 1", "k_column_solver_reg<0, 1, 1"], "vert_visc_3d": ["k_column_solver_reg<0, 0, 0"],
     "update_massflux_3d": ["k_massflux_lds"], "massflux_omega_new": ["k_massflux_omega_new"], "prsgrd": ["k_prsgrd_uv_tiled"], "rho_eos": ["k_rho_eos_P"], "rho_prsgrd": ["k_rho_prsgrd"],
-    "omega": ["k_omega_lds"], "massflux_omega": ["k_massflux_omega<"], "prestep_uv": ["k_prestep_uv2"], "stretch_transform": ["k_stretch_flat", "k_stretch"],
+    "omega": ["k_omega_lds"], "massflux_omega": ["k_massflux_omega<"], "prestep_uv": ["k_prestep_uv2"], "stretch_transform": ["k_stretch"],
     "vmix": ["k_vmix"], "massflux_old": ["k_massflux_old"], "k2d_fused": ["k2d_fused"],
 }
 
@@ -99,8 +99,8 @@ def pmc_traffic(group, cells, build):
         ks = [v for k, v in t["kernels"].items() if k.startswith(pre)]
         if not ks:
             return None, f"kernel {pre} not in profiles/traffic_current.json"
-        # several instantiations of one kernel (u / v): average them; several kernels in a group: add them
-        tot += sum(v["read_bytes_per_launch"] + v["write_bytes_per_launch"] for v in ks) / len(ks)
+        # several instantiations of one kernel (u / v, the modes of k2d_fused): mean over their launches; several kernels in a group: add them
+        tot += sum(v["launches"] * (v["read_bytes_per_launch"] + v["write_bytes_per_launch"]) for v in ks) / sum(v["launches"] for v in ks)
     if group == "uv_corrector":
         tot /= 2.0                  # its two entries are the two instantiations of one per-velocity launch
     return tot, f"profiles/traffic_current.json (build {build})"

@@ -20,8 +20,10 @@ for g, pres in bench.GROUP_KERNELS.items():
     ks = [k for k in st if any(k.startswith(p) for p in pres)]
     if not ks:
         continue
-    ms = sum(st[k][1] for k in ks) / len(ks)                      # instantiations of one launch (u / v): their mean
-    moved = sum(tr[k]["read_bytes_per_launch"] + tr[k]["write_bytes_per_launch"] for k in ks if k in tr) / max(1, len([k for k in ks if k in tr]))
+    ncall = sum(st[k][0] for k in ks)
+    ms = sum(st[k][0] * st[k][1] for k in ks) / ncall             # instantiations of one launch (u / v, the modes of k2d_fused): mean over their launches
+    kt = [k for k in ks if k in tr]
+    moved = sum(tr[k]["launches"] * (tr[k]["read_bytes_per_launch"] + tr[k]["write_bytes_per_launch"]) for k in kt) / max(1, sum(tr[k]["launches"] for k in kt))
     algo = bench.K2D_DOUBLES * 8 * cols if g == "k2d_fused" else bench.ALGO_DOUBLES[g] * 8 * cells
     if moved < 0.2 * algo:
         continue                                                   # launches over thin strips of the box (wall and ghost faces)
