@@ -436,7 +436,13 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
         if (CK) { v.A = 0.0; v.Ax = 0.0; } else { v.A = Akv(ic, j, kc + 1); v.Ax = ld2(Akv, kc + 1); }
         return v;
     };
-    double cf[VV_NZMAX], dc[VV_NZMAX], hzk[VV_NZMAX];
+    // deeper than 50 levels the three per-level register arrays no longer fit beside the load rings (22-58 registers spilled at 64): the
+    // thickness of the levels from KS up goes to LDS behind sX (40 KB a wave at 64 levels: four waves still share a CU)
+    constexpr int KS = NZ > 50 ? 50 : NZ;
+    double *sH = vv_lds + NZ * 64 + lane;
+    double cf[VV_NZMAX], dc[VV_NZMAX], hzk[KS];
+#define HZ_GET(k) ((k) < KS ? hzk[(k) < KS ? (k) : 0] : sH[((k) - KS) * 64])
+#define HZ_SET(k, v) do { if ((k) < KS) hzk[(k) < KS ? (k) : 0] = (v); else sH[((k) - KS) * 64] = (v); } while (0)
     double Hzk_m, AK_m, AK_0, phi_m;
     {
         const double h = Hz(ic, j, 0), hx = ld2(Hz, 0);
@@ -453,6 +459,7 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
     double CFp = 0.0, DCp = 0.0, oHz_m = 1.0 / Hzk_m;
     double CFraw_m = CK ? sixth * Hzk_m - dt * AK_m / Hzk_m : 0.0;       // CK: what FC(1) is
     cf[0] = 0.0; dc[0] = 0.0; hzk[0] = FULL ? Hzk_m : oHz_m;
+    static_assert(KS >= 1, "level 0 stays in a register");
     sX[0] = phi_m;
     ColLvl ring[D];
 #pragma unroll
@@ -475,7 +482,7 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
         const double cff = 1.0 / (BC - FC * CFp);
         CF *= cff;
         const double DC = cff * (phi_0 - phi_m - FC * DCp);
-        cf[k] = CF; dc[k] = DC; hzk[k] = FULL ? Hzk_0 : oHz;      // tracers only ever need the reciprocal again
+        cf[k] = CF; dc[k] = DC; HZ_SET(k, FULL ? Hzk_0 : oHz);      // tracers only ever need the reciprocal again
         sX[k * 64] = phi_0;
         __builtin_amdgcn_sched_barrier(0);
         ring[(k - 1) % D] = load_f(k + D);
@@ -503,7 +510,7 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
             const double DCs = DC * AKk;
             // FULL: the thickness itself is kept (the depth mean needs it) and its reciprocal is formed again here -- through an opaque
             // move, or hipcc recognises the quotient of the way up and keeps all NZ of them alive instead (100-128 more registers)
-            double Hzk = hzk[k];
+            double Hzk = HZ_GET(k);
             if (FULL) asm volatile("" : "+v"(Hzk));
             const double oHz = FULL ? 1.0 / Hzk : Hzk;
             const double cff = dt * oHz * (DCs_up - DCs);
@@ -526,7 +533,7 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
     // ---- vert_mean_3d: ascending sums in the reference's order (:22-34), then the correction (:36-46)
     double CF = hzk[0], DCm = sX[0] * CF;
 #pragma clang loop unroll(full)
-    for (int k = 1; k <= N; k++) { const double Hzf = hzk[k]; CF += Hzf; DCm += sX[k * 64] * Hzf; }
+    for (int k = 1; k <= N; k++) { const double Hzf = HZ_GET(k); CF += Hzf; DCm += sX[k * 64] * Hzf; }
     const double on = 2.0 / (dxlen(ip - IO, jj, 0) + dxlen(ip, j, 0));
     const double cff1 = 1.0 / (CF * (on));
     DCm = (DCm * (on) - Davg1(ip, j, 0)) * cff1;
@@ -549,7 +556,7 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
     for (int k = 0; k < VV_NZMAX; k++) {
         double x = sX[k * 64]; x -= DCm; x *= m;
         if (act) phi(i, j, k) = x;
-        const double DCk = hon * (2.0 * hzk[k]);
+        const double DCk = hon * (2.0 * HZ_GET(k));
         DCs += DCk;
         const double hp = 0.5 * (hq[k % MD] + x * DCk);
         FCm += hp;
@@ -561,11 +568,13 @@ k_column_solver_reg(B3 bx, A4 phi, A4 rphi, A4 Hz, A4 Akv, A4 Davg1, A4 dxlen, A
     FCm = DCi * (FCm - mf.Davg2(ip, j, 0));
     if (mfa) {
 #pragma clang loop unroll(full)
-        for (int k = 0; k < VV_NZMAX; k++) mf.Hphi(i, j, k) = sX[k * 64] - (hon * (2.0 * hzk[k])) * FCm;
+        for (int k = 0; k < VV_NZMAX; k++) mf.Hphi(i, j, k) = sX[k * 64] - (hon * (2.0 * HZ_GET(k))) * FCm;
         const double pb = DCi * a1;
         mf.phibar(i, j, 0, 0) = pb; mf.phibar(i, j, 0, 1) = pb;
     }
 }
+#undef HZ_GET
+#undef HZ_SET
 static inline bool vv_reg_depth(int nz) { return nz == 13 || nz == 16 || nz == 50 || nz == 64; }
 #define VV_D_T 16      // ring depth, tracers (3 loads per level)
 #define VV_D_V 10      // ring depth, v (6 loads per level)
@@ -594,7 +603,7 @@ int vert_visc_3d_view(rh_ctx *c, rh_box phi_bx, int ioff, int joff, rh_array4 ph
         const dim3 gridu((phi_bx.hi[0] - phi_bx.lo[0] + 63) / 63, phi_bx.hi[1] - phi_bx.lo[1] + 1, 1);     // u waves overlap by one column
         const A4 z = mkA(phi);                           // unused operands of the FULL form
         MfTail mfz; memset(&mfz, 0, sizeof mfz);
-        const size_t lds_reg = sizeof(double) * (size_t)(N + 1) * 64;
+        const size_t lds_reg = sizeof(double) * (size_t)(N + 1 + (N + 1 > 50 ? N + 1 - 50 : 0)) * 64;   // + the thickness of the levels from 50 up (k_column_solver_reg: KS)
         if (vv_reg_depth(N + 1) && !c->noregsolve) {     // a depth the register form is built for: no operand is read twice
             double akc = 0.0;
             const bool ck = vmix_row_value(c, akA, &akc) && !c->no_ckonst;
@@ -637,7 +646,7 @@ int launch_uv_corrector(rh_ctx *c, rh_state *s, int istep, int *applied)
     RH_NEED(s->DU_avg1, bx_slab(xbx, 2, 0)); RH_NEED(s->DV_avg1, bx_slab(ybx, 2, 0)); RH_NEED(s->msku, bx_slab(xbx, 2, 0)); RH_NEED(s->mskv, bx_slab(ybx, 2, 0));
     const dim3 gx((xbx.hi[0] - xbx.lo[0] + 63) / 63, xbx.hi[1] - xbx.lo[1] + 1, 1), gy((ybx.hi[0] - ybx.lo[0] + 64) / 64, ybx.hi[1] - ybx.lo[1] + 1, 1);
     const bool reg = vv_reg_depth(N + 1) && !c->noregsolve;
-    const size_t lds_reg = sizeof(double) * (size_t)(N + 1) * 64;
+    const size_t lds_reg = sizeof(double) * (size_t)(N + 1 + (N + 1 > 50 ? N + 1 - 50 : 0)) * 64;   // + the thickness of the levels from 50 up (k_column_solver_reg: KS)
     // update_massflux_3d rides on the same sweep (the column's final velocity and thickness are in LDS when the corrector ends):
     // *applied = 2 tells the caller to run update_massflux_3d only on what this launch leaves out (ghost faces, wall faces)
     MfTail mfu, mfv; memset(&mfu, 0, sizeof mfu); memset(&mfv, 0, sizeof mfv);
