@@ -1314,30 +1314,33 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
     const ColPtr cu = col_ptr_any(uold, i, j), cv = col_ptr_any(vold, i, j), cHu = col_ptr_any(Huon, i, j), cHv = col_ptr_any(Hvom, i, j), cHz = col_ptr_any(Hz, i, j),
                  cW = col_ptr_any(W, i, j), cru = au ? col_ptr(ru, i, j, nrhs) : ColPtr{ru.p, 0}, crv = av ? col_ptr(rv, i, j, nrhs) : ColPtr{rv.p, 0};
     const ColPtr qu = halo_ptr_any(uold, hu), qv = halo_ptr_any(vold, hv), qHu = halo_ptr_any(Huon, hHu), qHv = halo_ptr_any(Hvom, hHv), qW = halo_ptr_any(W, hW), qHz = halo_ptr_any(Hz, hHz);
-    // vertical windows q(k-1), q(k), q(k+1), q(k+2) of the own point
-    double um1 = 0.0, u0 = col_ldu(cu, 0), up1 = col_ldu(cu, 1), up2 = col_ldu(cu, 2 <= N ? 2 : N);
-    double vm1 = 0.0, v0 = col_ldu(cv, 0), vp1 = col_ldu(cv, 1), vp2 = col_ldu(cv, 2 <= N ? 2 : N);
-    double Hu0 = col_ldu(cHu, 0), Hv0 = col_ldu(cHv, 0), hz = col_ldu(cHz, 0), W1 = col_ldu(cW, 1);
-    double uh = col_ldu(qu, 0), vh = col_ldu(qv, 0), Huh = col_ldu(qHu, 0), Hvh = col_ldu(qHv, 0), Wh = col_ldu(qW, 1), hzh = col_ldu(qHz, 0);
-    double rru = col_ldu(cru, 0), rrv = col_ldu(crv, 0);
+    // vertical windows q(k-1), q(k), q(k+1), q(k+2) of the own point (the top entry arrives with the level's operand set)
+    double um1 = 0.0, u0 = col_ldu(cu, 0), up1 = col_ldu(cu, 1 <= N ? 1 : N), up2 = 0.0;
+    double vm1 = 0.0, v0 = col_ldu(cv, 0), vp1 = col_ldu(cv, 1 <= N ? 1 : N), vp2 = 0.0;
+    // The operands of level k, requested TWO levels ahead (two register sets, the loop unrolled by two; see k_tracers_tiled): own
+    // points and halo cells of Huon, Hvom, Hz, W(k + 1), the halo cells of uold / vold, ru / rv, and the own point of uold / vold at
+    // k + 2, the new top of the vertical window.
+    struct Lv { double un, vn, Hu, Hv, hz, W1, uh, vh, Huh, Hvh, Wh, hzh, ru, rv; };
+    auto load = [&](int k) -> Lv {
+        const int kc = k <= N ? k : N, k2 = k + 2 <= N ? k + 2 : N;
+        Lv q;
+        q.un = col_ldu(cu, k2); q.vn = col_ldu(cv, k2);
+        q.Hu = col_ldu(cHu, kc); q.Hv = col_ldu(cHv, kc); q.hz = col_ldu(cHz, kc); q.W1 = col_ldu(cW, kc + 1);
+        q.uh = col_ldu(qu, kc); q.vh = col_ldu(qv, kc); q.Huh = col_ldu(qHu, kc); q.Hvh = col_ldu(qHv, kc);
+        q.Wh = col_ldu(qW, kc + 1); q.hzh = col_ldu(qHz, kc);
+        q.ru = col_ldu(cru, kc); q.rv = col_ldu(crv, kc);
+        return q;
+    };
     double FCu = 0.0, FCv = 0.0;
-    for (int k = 0; k <= N; k++) {
+    auto level = [&](int k, Lv &S, int knext) {
         double *set = lds + (k & 1) * SET;
         double *su = set, *sv = su + T2::SIZE, *sHu = sv + T2::SIZE, *sHv = sHu + T2::SIZE, *sW = sHv + T2::SIZE, *sHz = sW + T2::SIZE;
-        tile_put<2, 2>(su, tx, ty, u0, hu, uh); tile_put<2, 2>(sv, tx, ty, v0, hv, vh);
-        tile_put<2, 2>(sHu, tx, ty, Hu0, hHu, Huh); tile_put<2, 2>(sHv, tx, ty, Hv0, hHv, Hvh);
-        tile_put<2, 2>(sW, tx, ty, W1, hW, Wh); tile_put<1, 1>(sHz, tx, ty, hz, hHz, hzh);
-        // ---- prefetch level k+1
-        // levels past the top are clamped: what they load feeds only the iteration that does not exist (window values past N are
-        // never read: win_FCw)
-        const int k1 = k + 1 <= N ? k + 1 : N, k3 = k + 3 <= N ? k + 3 : N;
-        const double u_n = col_ldu(cu, k3), v_n = col_ldu(cv, k3);
-        const double Hu0_n = col_ldu(cHu, k1), Hv0_n = col_ldu(cHv, k1), hz_n = col_ldu(cHz, k1);
-        const double W1_n = col_ldu(cW, k1 + 1);
-        const double uh_n = col_ldu(qu, k1), vh_n = col_ldu(qv, k1);
-        const double Huh_n = col_ldu(qHu, k1), Hvh_n = col_ldu(qHv, k1);
-        const double Wh_n = col_ldu(qW, k1 + 1), hzh_n = col_ldu(qHz, k1);
-        const double rru_n = col_ldu(cru, k1), rrv_n = col_ldu(crv, k1);
+        tile_put<2, 2>(su, tx, ty, u0, hu, S.uh); tile_put<2, 2>(sv, tx, ty, v0, hv, S.vh);
+        tile_put<2, 2>(sHu, tx, ty, S.Hu, hHu, S.Huh); tile_put<2, 2>(sHv, tx, ty, S.Hv, hHv, S.Hvh);
+        tile_put<2, 2>(sW, tx, ty, S.W1, hW, S.Wh); tile_put<1, 1>(sHz, tx, ty, S.hz, hHz, S.hzh);
+        const double hz = S.hz, W1 = S.W1, rru = S.ru, rrv = S.rv;
+        up2 = S.un; vp2 = S.vn;
+        S = load(knext);                                     // level k + 2 into the set that has just been consumed
         __syncthreads();
         const V2 tu{su, i0, j0}, tv{sv, i0, j0}, tHu{sHu, i0, j0}, tHv{sHv, i0, j0}, tW{sW, i0, j0};
         const V1 tHz{sHz, i0, j0};
@@ -1388,8 +1391,12 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
             frcv += c1 + c2;
             FCv = FCk1;
         }
-        um1 = u0; u0 = up1; up1 = up2; up2 = u_n; vm1 = v0; v0 = vp1; vp1 = vp2; vp2 = v_n;
-        Hu0 = Hu0_n; Hv0 = Hv0_n; hz = hz_n; W1 = W1_n; uh = uh_n; vh = vh_n; Huh = Huh_n; Hvh = Hvh_n; Wh = Wh_n; hzh = hzh_n; rru = rru_n; rrv = rrv_n;
+        um1 = u0; u0 = up1; up1 = up2; vm1 = v0; v0 = vp1; vp1 = vp2;
+    };
+    Lv A = load(0), B = load(1);
+    for (int k = 0; k <= N; k += 2) {
+        level(k, A, k + 2);
+        if (k + 1 <= N) level(k + 1, B, k + 3);
     }
     if (au) rufrc(i, j, 0) = frcu;
     if (av) rvfrc(i, j, 0) = frcv;
