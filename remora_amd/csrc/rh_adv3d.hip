@@ -1143,11 +1143,11 @@ k_tracers_tiled(B3 bx, A4 adv /* cons_old | sstore */, A4 cnew, A4 sst, A4 Hz, A
         for (int n = 0; n < RH_NCONS; n++) { wm1[n] = w0[n]; w0[n] = wp1[n]; wp1[n] = wp2[n]; }
         Wk = Wk1;
     };
+    // (no test inside the loop: a level that may be skipped would make every wait count after it conservative)
     Lv A = load(0), B = load(1);
-    for (int k = 0; k <= N; k += 2) {
-        level(k, A, k + 2);
-        if (k + 1 <= N) level(k + 1, B, k + 3);
-    }
+    int k = 0;
+    for (; k + 1 <= N; k += 2) { level(k, A, k + 2); level(k + 1, B, k + 3); }
+    if (k <= N) level(k, A, k + 2);
 }
 
 static int tracers_tiled(rh_ctx *c, rh_state *s, int mode, int iic, int ntfirst)

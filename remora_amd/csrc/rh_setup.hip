@@ -936,17 +936,21 @@ k_rho_prsgrd(B3 gb, B3 ub, B3 vb, B3 un, A4 st, A4 rhoA, A4 rhoS, A4 bvf, A4 Hz,
         sR[r3 * SZ + l0] = ra; sZ[r3 * SZ + l0] = v.z; sH[r3 * SZ + l0] = v.h; if (k < N) sP[((k + 1) & 1) * SZ + l0] = Pn;
     };
     Lvl a = load(N), b = load(N - 1);
-    for (int k = N; k >= 0; k -= 2) {
+    int k = N;
+    for (; k - 1 >= 0; k -= 2) {                            // two levels per trip, no test on the second (it would make the wait counts conservative)
         level(k, a);
         a = load(k - 2);
         __syncthreads();
         if (tile_wave && k < N) momentum(k + 1);
-        if (k - 1 >= 0) {
-            level(k - 1, b);
-            b = load(k - 3);
-            __syncthreads();
-            if (tile_wave) momentum(k);
-        }
+        level(k - 1, b);
+        b = load(k - 3);
+        __syncthreads();
+        if (tile_wave) momentum(k);
+    }
+    if (k >= 0) {                                           // an odd number of levels: the last one
+        level(k, a);
+        __syncthreads();
+        if (tile_wave && k < N) momentum(k + 1);
     }
     sP[l0] = rp_P0(q, cst);
     __syncthreads();
@@ -1393,11 +1397,11 @@ k_rhs_uv_tiled(B3 xb, B3 yb, B3 un, A4 uold, A4 vold, A4 ru, A4 rv, A4 rufrc, A4
         }
         um1 = u0; u0 = up1; up1 = up2; vm1 = v0; v0 = vp1; vp1 = vp2;
     };
+    // (no test inside the loop: a level that may be skipped would make every wait count after it conservative)
     Lv A = load(0), B = load(1);
-    for (int k = 0; k <= N; k += 2) {
-        level(k, A, k + 2);
-        if (k + 1 <= N) level(k + 1, B, k + 3);
-    }
+    int k = 0;
+    for (; k + 1 <= N; k += 2) { level(k, A, k + 2); level(k + 1, B, k + 3); }
+    if (k <= N) level(k, A, k + 2);
     if (au) rufrc(i, j, 0) = frcu;
     if (av) rvfrc(i, j, 0) = frcv;
 }
