@@ -13,7 +13,7 @@ int rh_fail(const char *fmt, ...)
     return 1;
 }
 extern "C" const char *rh_last_error(void) { return g_rh_err.c_str(); }
-#define RH_BUILD_ID "r3_v7"
+#define RH_BUILD_ID "r3_v8"
 extern "C" const char *rh_build_id(void) { return RH_BUILD_ID; }
 
 // ------------------------------------------------------------------------------------------------ timing
